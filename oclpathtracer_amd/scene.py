@@ -1,0 +1,184 @@
+"""Scene ingestion for the path-tracing hot path.
+
+Mirrors the host half of the reference harness:
+
+* ``load_model``      -- the ``cornellbox.bin`` reader + material table + quad split of
+                         ``test/RaytraceTest.cpp:87-198`` (``loadModel``).
+* ``TRIANGLE_DTYPE`` / ``MATERIAL_DTYPE`` -- the packed 64-byte device records of
+                         ``test/RaytraceTest.cpp:50-76`` / ``test/ClKernels/GenerateColors.cl:12-28``.
+* ``make_soup``       -- the synthetic 1M-triangle scene of BASELINE.json configs[4]
+                         (definition: SURVEY.md S8d, "C5").
+
+Fields the reference leaves uninitialised (``Material.roughness`` of diffuse surfaces, all
+padding) are zero here.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+DIFFUSE = 1
+SPECULAR = 2
+
+TRIANGLE_DTYPE = np.dtype(
+    [("p1", "<f4", 4), ("p2", "<f4", 4), ("p3", "<f4", 4), ("id", "<i4"), ("pad", "u1", 12)]
+)
+MATERIAL_DTYPE = np.dtype(
+    [("albedo", "<f4", 4), ("emissive", "<f4", 4), ("roughness", "<f4"), ("type", "<i4"), ("pad", "u1", 24)]
+)
+assert TRIANGLE_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 64
+
+DEFAULT_SCENE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cornellbox.bin")
+
+
+def parse_meshes(blob: bytes):
+    """Decode the little-endian mesh stream (RaytraceTest.cpp:117-143).
+
+    ``i32 nMesh`` then per mesh ``i32 nFaces, f32 albedoTag, nFaces x 4 i32, i32 nVerts,
+    nVerts x 4 f32``.  Returns a list of ``(tag, idx[nFaces,4], vtx[nVerts,4])``.
+    """
+    off = 0
+
+    def take(fmt):
+        nonlocal off
+        if off + struct.calcsize(fmt) > len(blob):
+            raise ValueError("scene file truncated")
+        (v,) = struct.unpack_from(fmt, blob, off)
+        off += struct.calcsize(fmt)
+        return v
+
+    meshes = []
+    n = take("<i")
+    if n < 0:
+        raise ValueError("negative mesh count")
+    for _ in range(n):
+        nf = take("<i")
+        tag = np.float32(take("<f"))
+        if nf < 0 or off + 16 * nf > len(blob):
+            raise ValueError("scene file truncated (faces)")
+        idx = np.frombuffer(blob, "<i4", nf * 4, off).reshape(nf, 4).copy()
+        off += 16 * nf
+        nv = take("<i")
+        if nv < 0 or off + 16 * nv > len(blob):
+            raise ValueError("scene file truncated (vertices)")
+        vtx = np.frombuffer(blob, "<f4", nv * 4, off).reshape(nv, 4).copy()
+        off += 16 * nv
+        if nf and (idx.min() < 0 or idx.max() >= nv):
+            raise ValueError("face index out of range")
+        meshes.append((tag, idx, vtx))
+    return meshes
+
+
+def load_model(path: str | None = None):
+    """Return ``(triangles, materials)`` as structured arrays (36 / 18 for the Cornell box).
+
+    Material assignment follows RaytraceTest.cpp:145-176: every mesh is DIFFUSE; a mesh whose
+    tag != 0.5 is the light (emissive 30, albedo 1, then overridden to 0.7 for meshes 0-2);
+    mesh 3 is red, mesh 4 green, mesh 5 the glossy boxes (SPECULAR, roughness 0.008, albedo
+    (0.5, 0.35, 0.05, 0)).  Each quad (a,b,c,d) becomes triangles (a,b,c) and (c,d,a) sharing
+    one material id (:186-193).
+    """
+    with open(path or DEFAULT_SCENE, "rb") as f:
+        meshes = parse_meshes(f.read())
+    tris = []
+    mats = []
+    mat_id = 0
+    for i, (tag, idx, vtx) in enumerate(meshes):
+        m = np.zeros((), MATERIAL_DTYPE)
+        m["type"] = DIFFUSE
+        if tag != np.float32(0.5):
+            m["emissive"] = (30.0, 30.0, 30.0, 1.0)
+            m["albedo"] = (1.0, 1.0, 1.0, 1.0)
+        else:
+            m["emissive"] = (0.0, 0.0, 0.0, 1.0)
+        if i in (0, 1, 2):
+            m["albedo"] = (0.7, 0.7, 0.7, 1.0)
+        if i == 3:
+            m["albedo"] = (0.6, 0.0, 0.0, 1.0)
+        if i == 4:
+            m["albedo"] = (0.0, 0.6, 0.0, 1.0)
+        if i == 5:
+            m["albedo"] = (0.5, 0.35, 0.05, 0.0)
+            m["roughness"] = 0.008
+            m["type"] = SPECULAR
+        for a, b, c, d in idx:
+            p = [np.array([vtx[k][0], vtx[k][1], vtx[k][2], 0.0], np.float32) for k in (a, b, c, d)]
+            for q in ((p[0], p[1], p[2]), (p[2], p[3], p[0])):
+                t = np.zeros((), TRIANGLE_DTYPE)
+                t["p1"], t["p2"], t["p3"] = q
+                t["id"] = mat_id
+                tris.append(t)
+            mats.append(m.copy())
+            mat_id += 1
+    triangles = np.array(tris, TRIANGLE_DTYPE) if tris else np.zeros(0, TRIANGLE_DTYPE)
+    materials = np.array(mats, MATERIAL_DTYPE) if mats else np.zeros(0, MATERIAL_DTYPE)
+    if len(triangles) // 2 != len(materials):  # the reference's only check (:197)
+        raise ValueError("triangle/material count mismatch")
+    return triangles, materials
+
+
+def _splitmix64(n: int, seed: int) -> np.ndarray:
+    """n successive splitmix64 outputs (vectorised)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def make_soup(ntri: int = 1_000_000, seed: int = 20261004, path: str | None = None):
+    """Cornell box + synthetic small-triangle soup.
+
+    Triangles 0..35 are the Cornell box; triangle i >= 36 has 24-bit uniforms
+    u = (x >> 40) * 2^-24 drawn from splitmix64(seed): centre c, p1 = c,
+    p2 = c + (2u-1)^3 * 0.02, p3 = c + (2u-1)^3 * 0.02, id = 18 + (i-36)//2;
+    materials 18.. are DIFFUSE with albedo 0.2 + 0.6u, emissive 0.
+    """
+    base_t, base_m = load_model(path)
+    if ntri < len(base_t):
+        raise ValueError("ntri must be >= 36")
+    extra = ntri - len(base_t)
+    nm_extra = (extra + 1) // 2
+    u = (_splitmix64(9 * extra + 3 * nm_extra, seed) >> np.uint64(40)).astype(np.float32) * np.float32(2.0**-24)
+    ut = u[: 9 * extra].reshape(extra, 9)
+    um = u[9 * extra :].reshape(nm_extra, 3)
+    tris = np.zeros(ntri, TRIANGLE_DTYPE)
+    tris[: len(base_t)] = base_t
+    lo = np.array([-2.7, 0.05, -5.5], np.float32)
+    span = np.array([5.4, 5.35, 5.4], np.float32)
+    c = lo + span * ut[:, 0:3]
+    d2 = (np.float32(2.0) * ut[:, 3:6] - np.float32(1.0)) * np.float32(0.02)
+    d3 = (np.float32(2.0) * ut[:, 6:9] - np.float32(1.0)) * np.float32(0.02)
+    t = tris[len(base_t) :]
+    t["p1"][:, :3] = c
+    t["p2"][:, :3] = c + d2
+    t["p3"][:, :3] = c + d3
+    t["id"] = 18 + np.arange(extra, dtype=np.int32) // 2
+    mats = np.zeros(len(base_m) + nm_extra, MATERIAL_DTYPE)
+    mats[: len(base_m)] = base_m
+    m = mats[len(base_m) :]
+    m["albedo"][:, :3] = np.float32(0.2) + np.float32(0.6) * um
+    m["albedo"][:, 3] = 1.0
+    m["emissive"][:, 3] = 1.0
+    m["type"] = DIFFUSE
+    return tris, mats
+
+
+def f2c(v: np.ndarray) -> np.ndarray:
+    """``f2c(sqrtf(v))`` of the reference's PPM writer (RaytraceTest.cpp:78-83, 280-285)."""
+    a = np.sqrt(np.asarray(v, np.float32)) * np.float32(255)
+    with np.errstate(invalid="ignore"):
+        b = np.where(np.isnan(a), np.float32(-2147483648.0), a)  # (int)NaN is INT_MIN on x86
+        b = np.clip(b, -2147483648.0, 2147483520.0).astype(np.int32)
+    return np.minimum(b, 255)  # int32: the reference prints its u32 with %d
+
+
+def write_ppm(path: str, fb: np.ndarray, W: int, H: int) -> None:
+    """Text 'P3' PPM exactly as RaytraceTest.cpp:277-287 writes it."""
+    c = f2c(fb.reshape(H * W, 4)[:, :3])
+    with open(path, "w") as f:
+        f.write("P3\n%d %d\n%d\n" % (W, H, 255))
+        f.write("".join("%d %d %d " % (r, g, b) for r, g, b in c))

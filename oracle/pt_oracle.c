@@ -1,0 +1,602 @@
+/*
+ * pt_oracle.c -- CPU restatement of the OclPathTracer hot path (TEST INFRASTRUCTURE).
+ *
+ * This file is the parity ORACLE for the HIP kernels in oclpathtracer_amd/csrc/ and the
+ * "port" CPU baseline timed by bench.py.  It is NOT part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  Nothing in
+ * oclpathtracer_amd/ includes, links or calls anything in this directory.
+ *
+ * What it restates (all citations relative to the reference repository):
+ *   test/ClKernels/GenerateColors.cl:47-322   the whole device kernel (RNG, camera,
+ *                                              Moeller-Trumbore, brute-force closest hit,
+ *                                              cosine / GGX sampling, <=16-bounce path loop,
+ *                                              gamma-space running mean)
+ *   test/RaytraceTest.cpp:50-76               64-byte Triangle / Material layouts
+ *   test/RaytraceTest.cpp:250-268             launch order: frame z = 0,1,2,... each over
+ *                                              all W*H work-items
+ *
+ * PARITY PINNING.  The reference holds no golden vectors, known-answer tests or pixel
+ * assertions for this path, its kernel cannot execute in the build
+ * container (no OpenCL device) and the OpenCL built-ins it calls (normalize, dot, cross,
+ * sin, cos, tan, pow, sqrt, "/") have implementation-defined rounding.  Against the real
+ * OpenCL output this oracle is therefore "parity unpinned".  It is pinned instead by the
+ * hand-derivable known answers of SURVEY.md S8c (tests/test_oracle_kat.py): the integer
+ * RNG/hash values, the camera constants, the decoded scene table and the behavioural
+ * invariants of intersectWorld / accumulate.
+ *
+ * ARITHMETIC SPEC (PTSPEC) -- the choices OpenCL leaves open, fixed here and
+ * mirrored bit-for-bit by the HIP kernels:
+ *   - binary32, round-to-nearest-even, subnormals preserved, no contraction of user
+ *     expressions (compile with -ffp-contract=off); "/" and sqrt correctly rounded.
+ *   - dot(a,b)   = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ *   - cross(a,b) = ( fma(a.y,b.z, -(a.z*b.y)), fma(a.z,b.x, -(a.x*b.z)), fma(a.x,b.y, -(a.y*b.x)) )
+ *   - normalize(v) = v * (1.0f / sqrtf(dot(v,v)))
+ *   - max(a,b)   = (a < b) ? b : a            (OpenCL's formula; NaN in a is returned)
+ *   - sin, cos   : double-precision Cody-Waite + Taylor evaluation, rounded once to float
+ *   - pow(x,y)   : y == 2 -> x*x ; else exp2(y*log2(x)) evaluated in double, rounded once
+ *   - tan(0.5f*fov) is the constant 0x1.279a74p-1f (correctly rounded)
+ *   - the w lane of radiance/mask is dropped (never observable: GenerateColors.cl:293,299)
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ptor_constants.h"
+
+#define PTOR_INLINE static inline __attribute__((always_inline))
+/* one body, two ISA clones: the "fma" clone inlines vfmadd for the explicit fma calls,
+ * the default one calls libm's (also correctly rounded) fmaf/fma.  Results are identical. */
+#define PTOR_CLONES __attribute__((target_clones("default", "fma")))
+
+typedef struct { float x, y, z; } v3;
+
+enum { PTOR_DIFFUSE = 1, PTOR_SPECULAR = 2 };
+
+/* 64-byte records, GenerateColors.cl:12-28 / RaytraceTest.cpp:50-76 */
+typedef struct { float p1[4], p2[4], p3[4]; int32_t id; char pad[12]; } ptor_triangle;
+typedef struct { float albedo[4], emissive[4]; float roughness; int32_t type; char pad[24]; } ptor_material;
+
+/* work tallies (SURVEY.md S8d "algorithmic work per sample") */
+typedef struct {
+    uint64_t samples;      /* (pixel, frame) paths                                  */
+    uint64_t rays;         /* intersectWorld calls (= bounces traced)               */
+    uint64_t tests;        /* intersectTriangle calls                               */
+    uint64_t cull;         /* returned at the det test      (GenerateColors.cl:100) */
+    uint64_t rej_u;        /* returned at the u test        (:109)                  */
+    uint64_t rej_v;        /* returned at the v test        (:117)                  */
+    uint64_t reach_t;      /* reached the t computation     (:122)                  */
+    uint64_t accept;       /* accepted as new closest hit   (:125)                  */
+    uint64_t shade_diffuse;
+    uint64_t shade_specular;
+    uint64_t miss;         /* paths ended on background     (:233)                  */
+    uint64_t term_pdf;     /* paths ended on pdf <= 0       (:251)                  */
+    uint64_t term_depth;   /* paths that used all bounces                           */
+} ptor_stats;
+
+/* ------------------------------------------------------------------ scalar helpers */
+PTOR_INLINE float ptor_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PTOR_INLINE double ptor_fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+PTOR_INLINE float ptor_max(float a, float b) { return (a < b) ? b : a; } /* OpenCL max() */
+
+PTOR_INLINE v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+PTOR_INLINE v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTOR_INLINE v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTOR_INLINE v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+PTOR_INLINE v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+
+PTOR_INLINE float v3_dot(v3 a, v3 b)
+{
+    return ptor_fma(a.z, b.z, ptor_fma(a.y, b.y, a.x * b.x));
+}
+PTOR_INLINE v3 v3_cross(v3 a, v3 b)
+{
+    return v3_make(ptor_fma(a.y, b.z, -(a.z * b.y)),
+                   ptor_fma(a.z, b.x, -(a.x * b.z)),
+                   ptor_fma(a.x, b.y, -(a.y * b.x)));
+}
+PTOR_INLINE v3 v3_normalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(v3_dot(a, a));
+    return v3_scale(a, inv);
+}
+
+/* ------------------------------------------------------------------ RNG (GenerateColors.cl:47-71) */
+PTOR_INLINE uint32_t ptor_hash_u32(uint32_t x) { return 1103515245u * x + 12345u; } /* :57, the #else branch */
+
+PTOR_INLINE float ptor_random_float(uint32_t* seed)
+{
+    uint32_t s = *seed;
+    s = (s ^ 61u) ^ (s >> 16);
+    s = s + (s << 3);
+    s = s ^ (s >> 4);
+    s = s * 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    s = 1103515245u * s + 12345u;
+    *seed = s;
+    return (float)s * 2.3283064365386963e-10f; /* u32 -> f32 rounds to nearest: range [0, 1] */
+}
+
+/* ------------------------------------------------------------------ transcendental helpers (PTSPEC) */
+/* sin and cos of a float angle phi >= 0 (the path only uses phi = TWO_PI * xi, xi in [0,1]). */
+PTOR_INLINE void ptor_sincos(float phi, float* s_out, float* c_out)
+{
+    double x = (double)phi;
+    int k = (int)(x * PTOR_TWO_OVER_PI + 0.5);
+    double kd = (double)k;
+    double r = ptor_fmad(-kd, PTOR_PIO2_HI, x);
+    r = ptor_fmad(-kd, PTOR_PIO2_LO, r);
+    double r2 = r * r;
+    double ps = PTOR_SIN_S6;
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S5);
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S4);
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S3);
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S2);
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S1);
+    ps = ptor_fmad(ps, r2, PTOR_SIN_S0);
+    double sn = ptor_fmad(r * r2, ps, r);
+    double pc = PTOR_COS_C7;
+    pc = ptor_fmad(pc, r2, PTOR_COS_C6);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C5);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C4);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C3);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C2);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C1);
+    pc = ptor_fmad(pc, r2, PTOR_COS_C0);
+    double cs = ptor_fmad(r2, pc, 1.0);
+    double so, co;
+    switch (k & 3) {
+    case 0: so = sn; co = cs; break;
+    case 1: so = cs; co = -sn; break;
+    case 2: so = -sn; co = -cs; break;
+    default: so = -cs; co = sn; break;
+    }
+    *s_out = (float)so;
+    *c_out = (float)co;
+}
+
+/* pow(x, y) for the two uses of the path: y == 2 (GGX denominator, :177) and the gamma
+ * exponents 2.2f and 1/2.2f (:292,:298), y > 0. */
+PTOR_INLINE float ptor_pow(float x, float y)
+{
+    if (y == 2.0f) return x * x;
+    if (!(x > 0.0f)) {
+        if (x == 0.0f) return 0.0f;
+        return __builtin_nanf(""); /* negative or NaN base */
+    }
+    if (x == __builtin_inff()) return x;
+    double xd = (double)x; /* exact; float subnormals are normal doubles */
+    uint64_t bits;
+    memcpy(&bits, &xd, 8);
+    int e = (int)(bits >> 52) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > PTOR_SQRT2) { m = m * 0.5; e = e + 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = PTOR_LOG2_L8;
+    p = ptor_fmad(p, s2, PTOR_LOG2_L7);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L6);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L5);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L4);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L3);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L2);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L1);
+    p = ptor_fmad(p, s2, PTOR_LOG2_L0);
+    double l = ptor_fmad(s, p, (double)e); /* log2(x) */
+    double t = (double)y * l;
+    if (t >= 130.0) return __builtin_inff();
+    if (t <= -160.0) return 0.0f;
+    int k = (int)(t + (t < 0.0 ? -0.5 : 0.5)); /* round half away; |k| <= 160 */
+    double f = t - (double)k;                  /* exact, |f| <= 0.5 */
+    double q = PTOR_EXP2_E12;
+    q = ptor_fmad(q, f, PTOR_EXP2_E11);
+    q = ptor_fmad(q, f, PTOR_EXP2_E10);
+    q = ptor_fmad(q, f, PTOR_EXP2_E9);
+    q = ptor_fmad(q, f, PTOR_EXP2_E8);
+    q = ptor_fmad(q, f, PTOR_EXP2_E7);
+    q = ptor_fmad(q, f, PTOR_EXP2_E6);
+    q = ptor_fmad(q, f, PTOR_EXP2_E5);
+    q = ptor_fmad(q, f, PTOR_EXP2_E4);
+    q = ptor_fmad(q, f, PTOR_EXP2_E3);
+    q = ptor_fmad(q, f, PTOR_EXP2_E2);
+    q = ptor_fmad(q, f, PTOR_EXP2_E1);
+    q = ptor_fmad(q, f, PTOR_EXP2_E0);
+    uint64_t sb = (uint64_t)(int64_t)(k + 1023) << 52; /* 2^k as a double, k in [-160,130] */
+    double sc;
+    memcpy(&sc, &sb, 8);
+    return (float)(q * sc); /* one rounding to float (overflow -> inf, subnormal floats exact) */
+}
+
+/* ------------------------------------------------------------------ rays (GenerateColors.cl:73-87, 263-288) */
+typedef struct { v3 origin, dir; } ptor_ray; /* invDir / sign (:80-84) are never read: dropped */
+
+PTOR_INLINE ptor_ray ptor_get_ray(v3 origin, v3 dir)
+{
+    ptor_ray r;
+    r.origin = origin;
+    r.dir = v3_normalize(dir);
+    return r;
+}
+
+#define PTOR_TWO_PI 6.28318530718f
+#define PTOR_INV_PI 0.31830988618f
+#define PTOR_TAN_HALF_FOV 0x1.279a74p-1f /* tan(0.5f * fov) correctly rounded, fov = (float)((60.0f*M_PI)/180.0f) */
+
+PTOR_INLINE ptor_ray ptor_generate_ray(int xc, int yc, int width, int height, uint32_t* seed)
+{
+    float invWidth = 1.0f / (float)width, invHeight = 1.0f / (float)height;
+    float aspectratio = (float)width / (float)height;
+    float angle = PTOR_TAN_HALF_FOV;
+
+    const v3 eye = v3_make(0.0f, 2.75f, 4.0f);
+    const v3 center = v3_add(eye, v3_make(0.0f, 0.0f, -1.0f));
+    const v3 up = v3_make(0.0f, 1.0f, 0.0f);
+
+    const v3 viewDir = v3_normalize(v3_sub(center, eye));
+    const v3 holDir = v3_normalize(v3_cross(viewDir, up));
+    const v3 upDir = v3_normalize(v3_cross(holDir, viewDir));
+
+    float x = (float)xc + ptor_random_float(seed) - 0.5f;
+    float y = (float)yc + ptor_random_float(seed) - 0.5f;
+
+    x = (2.0f * ((x + 0.5f) * invWidth) - 1.0f) * angle * aspectratio;
+    y = -(1.0f - 2.0f * ((y + 0.5f) * invHeight)) * angle;
+
+    float my = -1.0f * y;
+    v3 d = v3_add(v3_add(v3_scale(holDir, x), v3_scale(upDir, my)), viewDir);
+    v3 dir = v3_normalize(d);
+    v3 pointAimed = v3_add(eye, v3_scale(dir, 4.0f));
+    return ptor_get_ray(eye, v3_normalize(v3_sub(pointAimed, eye)));
+}
+
+/* ------------------------------------------------------------------ intersection (:89-154) */
+typedef struct { float t; v3 p, n; int tri; } ptor_hit;
+
+PTOR_INLINE int ptor_intersect_triangle(const ptor_ray* r, const ptor_triangle* tri, int tri_index,
+                                        ptor_hit* rec, float tmax, ptor_stats* st)
+{
+    v3 p1 = v3_make(tri->p1[0], tri->p1[1], tri->p1[2]);
+    v3 p2 = v3_make(tri->p2[0], tri->p2[1], tri->p2[2]);
+    v3 p3 = v3_make(tri->p3[0], tri->p3[1], tri->p3[2]);
+    v3 e1 = v3_sub(p2, p1);
+    v3 e2 = v3_sub(p3, p1);
+
+    v3 pvec = v3_cross(r->dir, e2);
+    float det = v3_dot(e1, pvec);
+    st->tests++;
+
+    if (det < 1e-8f || -det > 1e-8f) { st->cull++; return 0; } /* :100, literal form (NaN passes) */
+
+    float inv_det = 1.0f / det;
+    v3 tvec = v3_sub(r->origin, p1);
+    float u = v3_dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) { st->rej_u++; return 0; }
+
+    v3 qvec = v3_cross(tvec, e1);
+    float v = v3_dot(r->dir, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) { st->rej_v++; return 0; }
+
+    float t = v3_dot(e2, qvec) * inv_det;
+    v3 norm = v3_cross(e2, e1);
+    st->reach_t++;
+
+    if (t > 0.0f && t < tmax) {
+        rec->t = t;
+        rec->p = v3_add(r->origin, v3_scale(r->dir, t));
+        rec->tri = tri_index;
+        float w = 1.0f - u - v;
+        rec->n = v3_normalize(v3_add(v3_add(v3_scale(norm, u), v3_scale(norm, v)), v3_scale(norm, w)));
+        st->accept++;
+        return 1;
+    }
+    return 0;
+}
+
+PTOR_INLINE int ptor_intersect_world(const ptor_ray* r, const ptor_triangle* tris, int ntri,
+                                     ptor_hit* rec, ptor_stats* st)
+{
+    float hitDistance = 1e20f;
+    int isHit = 0;
+    st->rays++;
+    for (int i = 0; i < ntri; i++) {
+        if (ptor_intersect_triangle(r, &tris[i], i, rec, hitDistance, st)) {
+            hitDistance = rec->t;
+            isHit = 1;
+        }
+    }
+    return isHit;
+}
+
+/* ------------------------------------------------------------------ sampling (:156-221) */
+PTOR_INLINE v3 ptor_reflect(v3 v, v3 n)
+{
+    float k = 2.0f * v3_dot(v, n);
+    return v3_add(v3_neg(v), v3_scale(n, k));
+}
+
+PTOR_INLINE void ptor_basis(v3 n, v3* t, v3* s)
+{
+    v3 axis = fabsf(n.x) > 0.001f ? v3_make(0.0f, 1.0f, 0.0f) : v3_make(1.0f, 0.0f, 0.0f);
+    *t = v3_normalize(v3_cross(axis, n));
+    *s = v3_cross(n, *t);
+}
+
+PTOR_INLINE v3 ptor_sample_hemisphere_cosine(v3 n, uint32_t* seed)
+{
+    float phi = PTOR_TWO_PI * ptor_random_float(seed);
+    float sinThetaSqr = ptor_random_float(seed);
+    float sinTheta = sqrtf(sinThetaSqr);
+    v3 t, s;
+    ptor_basis(n, &t, &s);
+    float sp, cp;
+    ptor_sincos(phi, &sp, &cp);
+    float cz = sqrtf(1.0f - sinThetaSqr);
+    v3 a = v3_scale(v3_scale(s, cp), sinTheta);
+    v3 b = v3_scale(v3_scale(t, sp), sinTheta);
+    v3 c = v3_scale(n, cz);
+    return v3_normalize(v3_add(v3_add(a, b), c));
+}
+
+PTOR_INLINE float ptor_distribution_ggx(float cosTheta, float roughness)
+{
+    float roughness2 = roughness * roughness;
+    return roughness2 * PTOR_INV_PI / ptor_pow(cosTheta * cosTheta * (roughness2 - 1.0f) + 1.0f, 2.0f);
+}
+
+PTOR_INLINE v3 ptor_sample_ggx(v3 n, float roughness, float* cosTheta, uint32_t* seed)
+{
+    float phi = PTOR_TWO_PI * ptor_random_float(seed);
+    float xi = ptor_random_float(seed);
+    float ct = sqrtf((1.0f - xi) / (xi * (roughness * roughness - 1.0f) + 1.0f));
+    *cosTheta = ct;
+    float sinTheta = sqrtf(ptor_max(0.0f, 1.0f - ct * ct));
+    v3 t, s;
+    ptor_basis(n, &t, &s);
+    float sp, cp;
+    ptor_sincos(phi, &sp, &cp);
+    v3 a = v3_scale(v3_scale(s, cp), sinTheta);
+    v3 b = v3_scale(v3_scale(t, sp), sinTheta);
+    v3 c = v3_scale(n, ct);
+    return v3_normalize(v3_add(v3_add(a, b), c));
+}
+
+/* returns f (xyz); *pdf stays 0 on the specular early-out (:211) */
+PTOR_INLINE v3 ptor_brdf(v3 wo, v3* wi, float* pdf, v3 normal, const ptor_material* mat,
+                         uint32_t* seed, ptor_stats* st)
+{
+    v3 albedo = v3_make(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
+    if (mat->type == PTOR_DIFFUSE) {
+        st->shade_diffuse++;
+        *wi = ptor_sample_hemisphere_cosine(normal, seed);
+        *pdf = v3_dot(*wi, normal) * PTOR_INV_PI;
+        return v3_scale(albedo, PTOR_INV_PI);
+    } else if (mat->type == PTOR_SPECULAR) {
+        st->shade_specular++;
+        float cosTheta;
+        v3 wh = ptor_sample_ggx(normal, mat->roughness, &cosTheta, seed);
+        *wi = ptor_reflect(wo, wh);
+        if (v3_dot(*wi, normal) * v3_dot(wo, normal) < 0.0f) return v3_make(0.0f, 0.0f, 0.0f);
+        float D = ptor_distribution_ggx(cosTheta, mat->roughness);
+        *pdf = D * cosTheta / (4.0f * v3_dot(wo, wh));
+        float g = D / (4.0f * v3_dot(*wi, normal) * v3_dot(wo, normal));
+        return v3_scale(v3_scale(albedo, g), 2.0f);
+    }
+    return v3_make(0.0f, 0.0f, 0.0f);
+}
+
+/* ------------------------------------------------------------------ path loop (:223-261) */
+PTOR_INLINE v3 ptor_trace_rays(ptor_ray* r, const ptor_triangle* tris, int ntri,
+                               const ptor_material* mats, uint32_t* seed, int max_bounces,
+                               ptor_stats* st)
+{
+    v3 radiance = v3_make(0.0f, 0.0f, 0.0f);
+    v3 mask = v3_make(1.0f, 1.0f, 1.0f);
+    const float bg = ptor_max(0.45f, 0.0f);
+    int ended = 0;
+
+    for (int i = 0; i < max_bounces; ++i) {
+        ptor_hit rec;
+        if (!ptor_intersect_world(r, tris, ntri, &rec, st)) {
+            radiance = v3_add(radiance, v3_scale(mask, bg));
+            st->miss++;
+            ended = 1;
+            break;
+        }
+        const ptor_material* material = &mats[tris[rec.tri].id];
+        v3 em = v3_make(material->emissive[0], material->emissive[1], material->emissive[2]);
+        radiance.x = radiance.x + mask.x * em.x * 3.0f;
+        radiance.y = radiance.y + mask.y * em.y * 3.0f;
+        radiance.z = radiance.z + mask.z * em.z * 3.0f;
+
+        v3 n = v3_dot(rec.n, r->dir) < 0.0f ? rec.n : v3_scale(rec.n, -1.0f);
+
+        v3 wi = v3_make(0.0f, 0.0f, 0.0f);
+        v3 wo = v3_neg(r->dir);
+        float pdf = 0.0f;
+        v3 color = ptor_brdf(wo, &wi, &pdf, n, material, seed, st);
+
+        if (pdf <= 0.0f) { st->term_pdf++; ended = 1; break; }
+
+        float d = v3_dot(wi, n);
+        mask.x = mask.x * (color.x * d / pdf);
+        mask.y = mask.y * (color.y * d / pdf);
+        mask.z = mask.z * (color.z * d / pdf);
+
+        *r = ptor_get_ray(v3_add(rec.p, v3_scale(wi, 0.01f)), wi);
+    }
+    if (!ended) st->term_depth++;
+    return v3_make(ptor_max(radiance.x, 0.0f), ptor_max(radiance.y, 0.0f), ptor_max(radiance.z, 0.0f));
+}
+
+/* ------------------------------------------------------------------ one sample + accumulate (:302-321) */
+#define PTOR_GAMMA 2.2f
+PTOR_INLINE void ptor_sample_pixel(const ptor_triangle* tris, int ntri, const ptor_material* mats,
+                                   float* px /* float4 of this pixel */, int gid, int W, int H,
+                                   int frame, int max_bounces, ptor_stats* st)
+{
+    const int gi = gid % W;
+    const int gj = gid / W;
+    uint32_t seed = (uint32_t)gid + ptor_hash_u32((uint32_t)frame);
+    ptor_ray r = ptor_generate_ray(gi, gj, W, H, &seed);
+    v3 c = ptor_trace_rays(&r, tris, ntri, mats, &seed, max_bounces, st);
+    st->samples++;
+    const float inv_gamma = 1.0f / PTOR_GAMMA;
+    if (frame == 0) {
+        px[0] = ptor_pow(c.x, inv_gamma);
+        px[1] = ptor_pow(c.y, inv_gamma);
+        px[2] = ptor_pow(c.z, inv_gamma);
+        px[3] = 1.0f;
+    } else {
+        float zm1 = (float)(frame - 1), z = (float)frame;
+        float ox = ptor_pow(px[0], PTOR_GAMMA), oy = ptor_pow(px[1], PTOR_GAMMA), oz = ptor_pow(px[2], PTOR_GAMMA);
+        px[0] = ptor_pow((ox * zm1 + c.x) / z, inv_gamma);
+        px[1] = ptor_pow((oy * zm1 + c.y) / z, inv_gamma);
+        px[2] = ptor_pow((oz * zm1 + c.z) / z, inv_gamma);
+        px[3] = 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------ threaded driver */
+typedef struct {
+    const ptor_triangle* tris; int ntri; const ptor_material* mats;
+    float* fb; int W, H, frame_begin, frame_count, max_bounces;
+    int64_t gid_begin, gid_count;
+    int64_t* next_chunk; ptor_stats st;
+} ptor_job;
+
+#define PTOR_CHUNK 256
+
+PTOR_CLONES
+static void ptor_run_chunks(ptor_job* job)
+{
+    ptor_stats st;
+    memset(&st, 0, sizeof st);
+    for (;;) {
+        int64_t c = __atomic_fetch_add(job->next_chunk, 1, __ATOMIC_RELAXED);
+        int64_t b = c * PTOR_CHUNK;
+        if (b >= job->gid_count) break;
+        int64_t e = b + PTOR_CHUNK < job->gid_count ? b + PTOR_CHUNK : job->gid_count;
+        for (int64_t k = b; k < e; ++k) {
+            int gid = (int)(job->gid_begin + k);
+            /* frames in ascending order per pixel == the reference's frame-major launch order,
+             * because a pixel's value depends only on its own history (:314-321). */
+            for (int f = 0; f < job->frame_count; ++f)
+                ptor_sample_pixel(job->tris, job->ntri, job->mats, job->fb + 4 * (int64_t)gid, gid,
+                                  job->W, job->H, job->frame_begin + f, job->max_bounces, &st);
+        }
+    }
+    job->st = st;
+}
+
+static void* ptor_thread_main(void* arg) { ptor_run_chunks((ptor_job*)arg); return 0; }
+
+static void ptor_stats_add(ptor_stats* a, const ptor_stats* b)
+{
+    uint64_t* pa = (uint64_t*)a; const uint64_t* pb = (const uint64_t*)b;
+    for (size_t i = 0; i < sizeof(ptor_stats) / 8; ++i) pa[i] += pb[i];
+}
+
+/*
+ * Render frames [frame_begin, frame_begin+frame_count) of pixels gid in
+ * [gid_begin, gid_begin+gid_count) into the full-image framebuffer fb (W*H float4).
+ * tris / mats are the reference's raw 64-byte records.  stats may be NULL.
+ */
+int ptor_render(const void* tris, int ntri, const void* mats, int nmat, float* fb, int W, int H,
+                int frame_begin, int frame_count, int max_bounces, int64_t gid_begin,
+                int64_t gid_count, int nthreads, ptor_stats* stats)
+{
+    (void)nmat;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if (gid_begin < 0 || gid_count < 0 || gid_begin + gid_count > (int64_t)W * H) return -1;
+    int64_t next = 0;
+    ptor_job* jobs = (ptor_job*)calloc((size_t)nthreads, sizeof(ptor_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    for (int i = 0; i < nthreads; ++i) {
+        ptor_job j = { (const ptor_triangle*)tris, ntri, (const ptor_material*)mats, fb, W, H,
+                       frame_begin, frame_count, max_bounces, gid_begin, gid_count, &next, { 0 } };
+        jobs[i] = j;
+    }
+    for (int i = 1; i < nthreads; ++i) pthread_create(&th[i], 0, ptor_thread_main, &jobs[i]);
+    ptor_run_chunks(&jobs[0]);
+    for (int i = 1; i < nthreads; ++i) pthread_join(th[i], 0);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (int i = 0; i < nthreads; ++i) ptor_stats_add(stats, &jobs[i].st);
+    }
+    free(jobs);
+    free(th);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ unit entry points for the KATs */
+uint32_t ptor_kat_hash(uint32_t x) { return ptor_hash_u32(x); }
+
+PTOR_CLONES
+float ptor_kat_random(uint32_t* seed) { return ptor_random_float(seed); }
+
+PTOR_CLONES
+void ptor_kat_sincos(float phi, float* s, float* c) { ptor_sincos(phi, s, c); }
+
+PTOR_CLONES
+float ptor_kat_pow(float x, float y) { return ptor_pow(x, y); }
+
+PTOR_CLONES
+void ptor_kat_sincos_array(const float* phi, float* s, float* c, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) ptor_sincos(phi[i], &s[i], &c[i]);
+}
+
+PTOR_CLONES
+void ptor_kat_pow_array(const float* x, float y, float* out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = ptor_pow(x[i], y);
+}
+
+/* camera ray for pixel (xc,yc) with a given starting seed; out = origin xyz, dir xyz */
+PTOR_CLONES
+void ptor_kat_generate_ray(int xc, int yc, int W, int H, uint32_t* seed, float* out6)
+{
+    ptor_ray r = ptor_generate_ray(xc, yc, W, H, seed);
+    out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z;
+    out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
+}
+
+/* closest hit of a ray (direction is normalised by getRay as in the reference);
+ * returns hit flag; out = t, p xyz, n xyz ; *tri = triangle index */
+PTOR_CLONES
+int ptor_kat_intersect_world(const void* tris, int ntri, const float* origin, const float* dir,
+                             float* out7, int* tri)
+{
+    ptor_stats st;
+    memset(&st, 0, sizeof st);
+    ptor_ray r = ptor_get_ray(v3_make(origin[0], origin[1], origin[2]), v3_make(dir[0], dir[1], dir[2]));
+    ptor_hit rec;
+    memset(&rec, 0, sizeof rec);
+    rec.tri = -1;
+    int hit = ptor_intersect_world(&r, (const ptor_triangle*)tris, ntri, &rec, &st);
+    out7[0] = rec.t; out7[1] = rec.p.x; out7[2] = rec.p.y; out7[3] = rec.p.z;
+    out7[4] = rec.n.x; out7[5] = rec.n.y; out7[6] = rec.n.z;
+    *tri = rec.tri;
+    return hit;
+}
+
+/* radiance of one path (no accumulation): out = xyz */
+PTOR_CLONES
+void ptor_kat_radiance(const void* tris, int ntri, const void* mats, int gid, int W, int H, int frame,
+                       int max_bounces, float* out3)
+{
+    ptor_stats st;
+    memset(&st, 0, sizeof st);
+    uint32_t seed = (uint32_t)gid + ptor_hash_u32((uint32_t)frame);
+    ptor_ray r = ptor_generate_ray(gid % W, gid / W, W, H, &seed);
+    v3 c = ptor_trace_rays(&r, (const ptor_triangle*)tris, ntri, (const ptor_material*)mats, &seed,
+                           max_bounces, &st);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+
+int ptor_stats_words(void) { return (int)(sizeof(ptor_stats) / 8); }
+int ptor_has_fma_clone(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }
