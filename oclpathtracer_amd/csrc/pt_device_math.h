@@ -1,0 +1,150 @@
+// pt_device_math.h -- gfx950 device-side arithmetic of the path-tracing hot path.
+//
+// Implements the PTSPEC arithmetic contract for the OpenCL built-ins that
+// test/ClKernels/GenerateColors.cl calls and whose rounding OpenCL leaves open:
+//   dot / cross / normalize  (GenerateColors.cl:75,96-97,107,114-115,122-123,130,...)
+//   sin / cos                (:171,191)        pow (:177,292,298)       max (:185,235,260)
+// Every function is a fixed sequence of IEEE binary32 / binary64 operations (+,-,*,/,sqrt,
+// fma, integer ops); the translation unit is compiled with -ffp-contract=off and without
+// any fast-math flag, hipcc's default correctly-rounded fp32 divide/sqrt, subnormals kept.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_constants.h"
+
+#define PTK_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+
+PTK_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTK_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTK_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTK_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PTK_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+
+PTK_DEV float pt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PTK_DEV double pt_fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// OpenCL max(): (a < b) ? b : a  -- a NaN in `a` is returned, a NaN in `b` is dropped
+PTK_DEV float pt_max(float a, float b) { return (a < b) ? b : a; }
+
+// dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+PTK_DEV float dot3(f3 a, f3 b) { return pt_fma(a.z, b.z, pt_fma(a.y, b.y, a.x * b.x)); }
+
+// cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )
+PTK_DEV f3 cross3(f3 a, f3 b)
+{
+    return mk3(pt_fma(a.y, b.z, -(a.z * b.y)), pt_fma(a.z, b.x, -(a.x * b.z)), pt_fma(a.x, b.y, -(a.y * b.x)));
+}
+
+// normalize(v) = v * (1.0f / sqrtf(dot(v,v)))   (both correctly rounded)
+PTK_DEV f3 normalize3(f3 a)
+{
+    float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+    return scale3(a, inv);
+}
+
+// ---- RNG: GenerateColors.cl:47-71 -------------------------------------------------------
+PTK_DEV uint32_t pt_hash_u32(uint32_t x) { return 1103515245u * x + 12345u; }
+
+PTK_DEV float pt_random_float(uint32_t& seed)
+{
+    uint32_t s = seed;
+    s = (s ^ 61u) ^ (s >> 16);
+    s = s + (s << 3);
+    s = s ^ (s >> 4);
+    s = s * 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    s = 1103515245u * s + 12345u;
+    seed = s;
+    return (float)s * 2.3283064365386963e-10f;
+}
+
+// ---- sin/cos of phi >= 0: Cody-Waite by pi/2 in binary64, Taylor to r^15 / r^16, one rounding ----
+PTK_DEV void pt_sincos(float phi, float& s_out, float& c_out)
+{
+    double x = (double)phi;
+    int k = (int)(x * PTK_TWO_OVER_PI + 0.5);
+    double kd = (double)k;
+    double r = pt_fmad(-kd, PTK_PIO2_HI, x);
+    r = pt_fmad(-kd, PTK_PIO2_LO, r);
+    double r2 = r * r;
+    double ps = PTK_SIN_S6;
+    ps = pt_fmad(ps, r2, PTK_SIN_S5);
+    ps = pt_fmad(ps, r2, PTK_SIN_S4);
+    ps = pt_fmad(ps, r2, PTK_SIN_S3);
+    ps = pt_fmad(ps, r2, PTK_SIN_S2);
+    ps = pt_fmad(ps, r2, PTK_SIN_S1);
+    ps = pt_fmad(ps, r2, PTK_SIN_S0);
+    double sn = pt_fmad(r * r2, ps, r);
+    double pc = PTK_COS_C7;
+    pc = pt_fmad(pc, r2, PTK_COS_C6);
+    pc = pt_fmad(pc, r2, PTK_COS_C5);
+    pc = pt_fmad(pc, r2, PTK_COS_C4);
+    pc = pt_fmad(pc, r2, PTK_COS_C3);
+    pc = pt_fmad(pc, r2, PTK_COS_C2);
+    pc = pt_fmad(pc, r2, PTK_COS_C1);
+    pc = pt_fmad(pc, r2, PTK_COS_C0);
+    double cs = pt_fmad(r2, pc, 1.0);
+    int q = k & 3;
+    double so = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+    double co = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+    s_out = (float)so;
+    c_out = (float)co;
+}
+
+// ---- pow(x, y): y == 2 -> x*x ; else exp2(y*log2(x)) in binary64, one rounding -------------
+PTK_DEV float pt_pow(float x, float y)
+{
+    if (y == 2.0f) return x * x;
+    if (!(x > 0.0f)) {
+        if (x == 0.0f) return 0.0f;
+        return __builtin_nanf("");
+    }
+    if (x == __builtin_inff()) return x;
+    double xd = (double)x;
+    uint64_t bits = (uint64_t)__double_as_longlong(xd);
+    int e = (int)(bits >> 52) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __longlong_as_double((long long)bits);
+    if (m > PTK_SQRT2) { m = m * 0.5; e = e + 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = PTK_LOG2_L8;
+    p = pt_fmad(p, s2, PTK_LOG2_L7);
+    p = pt_fmad(p, s2, PTK_LOG2_L6);
+    p = pt_fmad(p, s2, PTK_LOG2_L5);
+    p = pt_fmad(p, s2, PTK_LOG2_L4);
+    p = pt_fmad(p, s2, PTK_LOG2_L3);
+    p = pt_fmad(p, s2, PTK_LOG2_L2);
+    p = pt_fmad(p, s2, PTK_LOG2_L1);
+    p = pt_fmad(p, s2, PTK_LOG2_L0);
+    double l = pt_fmad(s, p, (double)e);
+    double t = (double)y * l;
+    if (t >= 130.0) return __builtin_inff();
+    if (t <= -160.0) return 0.0f;
+    int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+    double f = t - (double)k;
+    double q = PTK_EXP2_E12;
+    q = pt_fmad(q, f, PTK_EXP2_E11);
+    q = pt_fmad(q, f, PTK_EXP2_E10);
+    q = pt_fmad(q, f, PTK_EXP2_E9);
+    q = pt_fmad(q, f, PTK_EXP2_E8);
+    q = pt_fmad(q, f, PTK_EXP2_E7);
+    q = pt_fmad(q, f, PTK_EXP2_E6);
+    q = pt_fmad(q, f, PTK_EXP2_E5);
+    q = pt_fmad(q, f, PTK_EXP2_E4);
+    q = pt_fmad(q, f, PTK_EXP2_E3);
+    q = pt_fmad(q, f, PTK_EXP2_E2);
+    q = pt_fmad(q, f, PTK_EXP2_E1);
+    q = pt_fmad(q, f, PTK_EXP2_E0);
+    uint64_t sb = (uint64_t)(int64_t)(k + 1023) << 52;
+    double sc = __longlong_as_double((long long)sb);
+    return (float)(q * sc);
+}
+
+#define PTK_TWO_PI 6.28318530718f
+#define PTK_INV_PI 0.31830988618f
+#define PTK_TAN_HALF_FOV 0x1.279a74p-1f  // tan(0.5f*fov), fov = (float)((60.0f*M_PI)/180.0f); correctly rounded
+#define PTK_GAMMA 2.2f

@@ -1,0 +1,59 @@
+// pt_kernels.h -- host-callable launchers of the gfx950 kernels (pt_kernels.hip).
+// Internal to libptshim.so; the public boundary is include/pt_shim.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// The reference's packed 64-byte device records (GenerateColors.cl:12-28).
+struct PtRawTriangle { float p1[4], p2[4], p3[4]; int32_t id; char pad[12]; };
+struct PtRawMaterial { float albedo[4], emissive[4]; float roughness; int32_t type; char pad[24]; };
+static_assert(sizeof(PtRawTriangle) == 64 && sizeof(PtRawMaterial) == 64, "record layout");
+
+// Triangle as the trace kernel consumes it: one 64-byte, 64-byte-aligned record =
+// one s_load_dwordx16 per wave.  e1 = p2-p1, e2 = p3-p1, n = cross(e2,e1) are the values
+// intersectTriangle recomputes on every call (GenerateColors.cl:92-93,123); computing them
+// once per upload yields the same bits.
+struct PtPrepTriangle {
+    float p1[3];
+    float e1[3];
+    float e2[3];
+    float pad0[3];
+    float n[3];
+    int32_t id;
+};
+static_assert(sizeof(PtPrepTriangle) == 64, "prep layout");
+
+#define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
+#define PT_TRACE_THREADS 256   // 4 waves per workgroup
+
+struct PtTraceParams {
+    const PtPrepTriangle* tris;
+    const PtRawMaterial* mats;
+    float4* rad;                  // [chunk_frames][npix_local] path radiance (max(L,0), w unused)
+    unsigned int* batch_counter;  // zeroed before the launch
+    unsigned long long* stats;    // may be null: [0] samples, [1] rays
+    int32_t width, height;
+    int32_t frame_begin;          // first frame of this chunk (global frame index)
+    int32_t frame_count;          // frames in this chunk
+    int32_t max_bounces, ntri, nmat;
+    int32_t stripe_rows, n_ranks, rank;
+    uint32_t npix_local;
+    uint32_t batches_per_frame, total_batches;
+};
+
+struct PtFoldParams {
+    const float4* rad;  // [frame_count][npix_local]
+    float4* fb;         // [npix_local] gamma-encoded running mean (GenerateColors.cl:314-321)
+    uint32_t npix_local;
+    int32_t frame_begin, frame_count;
+};
+
+hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, hipStream_t s);
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, hipStream_t s);
+hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);
+hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width, int height, int stripe_rows,
+                                int n_ranks, int slab_rows, hipStream_t s);
+hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStream_t s);
+hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s);
+int ptk_trace_blocks_per_cu(void);

@@ -1,0 +1,944 @@
+// pt_shim.hip -- implementation of the C ABI in include/pt_shim.h on the HIP runtime.
+//
+// Replaces, for the path-tracing hot path, what the reference does through
+// Adl/CL/AdlCL.{inl,cpp} + Adl/CL/AdlKernelUtilsCL.{inl,cpp} + Adl/AdlKernel.cpp
+// (OpenCL context/queue, cl_mem buffers, map/unmap, source->binary kernel cache,
+// clSetKernelArg + clEnqueueNDRangeKernel).  There is no CPU path in this file.
+#include "../../include/pt_shim.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pt_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(PT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* pt_last_error(void) { return g_err; }
+extern "C" int pt_abi_version(void) { return PT_SHIM_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------
+enum { KERNEL_GENERATE_COLORS = 0, KERNEL_FILL = 1, KERNEL_COUNT = 2 };
+
+struct pt_kernel_s {
+    int id;
+    const char* file;
+    const char* func;
+};
+
+struct pt_buffer_s {
+    pt_device_s* dev;
+    void* dptr;
+    size_t bytes;
+    bool owned;
+    uint64_t version;   // bumped by every API call that may change the contents
+    void* staging;      // pinned host range of the last map (kept until the buffer dies)
+    size_t staging_bytes;
+    bool mapped;
+};
+
+struct pt_event_s {
+    pt_device_s* dev;
+    hipEvent_t start, stop;
+    bool recorded;
+};
+
+struct PendingFrames {  // deferred GenerateColors launches (PT_OPT_BATCH_FRAMES)
+    bool active;
+    pt_buffer_s *tris, *mats, *fb;
+    int width, height, z_begin, z_count;
+    uint32_t pixel_count;
+};
+
+struct pt_device_s {
+    int idx;
+    hipDeviceProp_t prop;
+    hipStream_t own_stream, stream;
+    uint64_t used, peak;
+    int live_buffers;
+    int64_t opt_batch, opt_chunk, opt_profile;
+    pt_kernel_s kernels[KERNEL_COUNT];
+    // prepared-scene cache
+    PtPrepTriangle* prep;
+    size_t prep_capacity;  // triangles
+    const pt_buffer_s* prep_src;
+    uint64_t prep_version;
+    int prep_ntri;
+    // fused-render workspace
+    float4* rad;
+    size_t rad_bytes;
+    unsigned int* counters;  // PT_MAX_CHUNKS batch counters
+    int blocks_per_cu;
+    PendingFrames pending;
+    // per-kernel timing (pt_profile_*)
+    bool prof_on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* prof_pairs;  // [PT_PROF_KINDS]
+    size_t prof_used[PT_PROF_KINDS];
+};
+
+static int prof_begin(pt_device_s* d, int kind, hipEvent_t* stop_out)
+{
+    *stop_out = nullptr;
+    if (!d->prof_on) return PT_OK;
+    auto& v = d->prof_pairs[kind];
+    if (d->prof_used[kind] == v.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        v.push_back({ a, b });
+    }
+    auto& pr = v[d->prof_used[kind]++];
+    HIP_TRY(hipEventRecord(pr.first, d->stream));
+    *stop_out = pr.second;
+    return PT_OK;
+}
+
+static int prof_end(pt_device_s* d, hipEvent_t stop)
+{
+    if (stop) HIP_TRY(hipEventRecord(stop, d->stream));
+    return PT_OK;
+}
+
+#define PT_MAX_CHUNKS 4096
+
+static int g_init_count = 0;
+
+static int use_device(pt_device_s* d)
+{
+    if (!d) return fail(PT_ERR_INVALID, "null device handle");
+    HIP_TRY(hipSetDevice(d->idx));
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// library / device lifetime
+// ------------------------------------------------------------------------------------------
+extern "C" int pt_init(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    if (n <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
+    ++g_init_count;
+    return PT_OK;
+}
+
+extern "C" void pt_quit(void)
+{
+    if (g_init_count > 0) --g_init_count;
+}
+
+extern "C" int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pt_device_create(int device_idx, pt_device_t* out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device_idx < 0 || device_idx >= n) return fail(PT_ERR_NO_DEVICE, "device index %d out of range [0,%d)", device_idx, n);
+    pt_device_s* d = new (std::nothrow) pt_device_s();
+    if (!d) return fail(PT_ERR_OOM, "host allocation failed");
+    memset(static_cast<void*>(d), 0, sizeof *d);
+    d->idx = device_idx;
+    if (hipSetDevice(device_idx) != hipSuccess || hipGetDeviceProperties(&d->prop, device_idx) != hipSuccess) {
+        delete d;
+        return fail(PT_ERR_HIP, "cannot open device %d", device_idx);
+    }
+    if (strncmp(d->prop.gcnArchName, "gfx950", 6) != 0) {
+        char arch[64];
+        snprintf(arch, sizeof arch, "%s", d->prop.gcnArchName);
+        delete d;
+        return fail(PT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device_idx, arch);
+    }
+    if (hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete d;
+        return fail(PT_ERR_HIP, "hipStreamCreate failed");
+    }
+    d->stream = d->own_stream;
+    d->opt_batch = 1;
+    d->opt_chunk = 0;
+    d->opt_profile = 0;
+    d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
+    d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
+    if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess) {
+        hipStreamDestroy(d->own_stream);
+        delete d;
+        return fail(PT_ERR_OOM, "workspace allocation failed");
+    }
+    d->blocks_per_cu = ptk_trace_blocks_per_cu();
+    d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
+    *out = d;
+    return PT_OK;
+}
+
+static int flush_pending(pt_device_s* d);
+
+extern "C" int pt_device_destroy(pt_device_t d)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    rc = flush_pending(d);
+    hipStreamSynchronize(d->stream);
+    if (d->live_buffers != 0)
+        return fail(PT_ERR_INVALID, "%d buffer(s) of this device are still alive", d->live_buffers);
+    if (d->prep) hipFree(d->prep);
+    if (d->rad) hipFree(d->rad);
+    if (d->counters) hipFree(d->counters);
+    for (int k = 0; k < PT_PROF_KINDS; ++k)
+        for (auto& pr : d->prof_pairs[k]) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    delete[] d->prof_pairs;
+    hipStreamDestroy(d->own_stream);
+    delete d;
+    return rc;
+}
+
+extern "C" int pt_device_info(pt_device_t d, int kind, char out[128])
+{
+    if (!d || !out) return fail(PT_ERR_INVALID, "null argument");
+    out[0] = 0;
+    switch (kind) {
+    case PT_INFO_NAME:
+    case PT_INFO_BOARD: snprintf(out, 128, "%s", d->prop.name); break;
+    case PT_INFO_VENDOR: snprintf(out, 128, "Advanced Micro Devices, Inc."); break;
+    case PT_INFO_VERSION: {
+        int rt = 0;
+        hipRuntimeGetVersion(&rt);
+        snprintf(out, 128, "HIP %d %.*s", rt, 96, d->prop.gcnArchName);
+        break;
+    }
+    default: return fail(PT_ERR_INVALID, "unknown info kind %d", kind);
+    }
+    return PT_OK;
+}
+
+extern "C" uint64_t pt_device_max_alloc(pt_device_t d) { return d ? (uint64_t)d->prop.totalGlobalMem : 0; }
+extern "C" uint64_t pt_device_mem_size(pt_device_t d) { return d ? (uint64_t)d->prop.totalGlobalMem : 0; }
+extern "C" uint64_t pt_device_used_memory(pt_device_t d) { return d ? d->used : 0; }
+extern "C" uint64_t pt_device_peak_memory(pt_device_t d) { return d ? d->peak : 0; }
+extern "C" int pt_device_num_cus(pt_device_t d) { return d ? d->prop.multiProcessorCount : 0; }
+
+extern "C" int pt_device_set_stream(pt_device_t d, void* hip_stream)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    rc = flush_pending(d);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));  // keep the one-queue ordering across the switch
+    d->stream = hip_stream ? (hipStream_t)hip_stream : d->own_stream;
+    return PT_OK;
+}
+
+extern "C" void* pt_device_get_stream(pt_device_t d) { return d ? (void*)d->stream : nullptr; }
+
+extern "C" int pt_sync(pt_device_t d)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return PT_OK;
+}
+
+extern "C" int pt_flush(pt_device_t d)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    return flush_pending(d);
+}
+
+extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    switch (option) {
+    case PT_OPT_BATCH_FRAMES:
+        rc = flush_pending(d);
+        d->opt_batch = value ? 1 : 0;
+        return rc;
+    case PT_OPT_CHUNK_FRAMES:
+        if (value < 0) return fail(PT_ERR_INVALID, "chunk frames must be >= 0");
+        d->opt_chunk = value;
+        return PT_OK;
+    case PT_OPT_PROFILE_RETURN_TIME:
+        d->opt_profile = value ? 1 : 0;
+        return PT_OK;
+    default: return fail(PT_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
+{
+    if (!d) return -1;
+    switch (option) {
+    case PT_OPT_BATCH_FRAMES: return d->opt_batch;
+    case PT_OPT_CHUNK_FRAMES: return d->opt_chunk;
+    case PT_OPT_PROFILE_RETURN_TIME: return d->opt_profile;
+    default: return -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------
+extern "C" int pt_buffer_alloc(pt_device_t d, size_t bytes, pt_buffer_t* out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    int rc = use_device(d);
+    if (rc) return rc;
+    pt_buffer_s* b = new (std::nothrow) pt_buffer_s();
+    if (!b) return fail(PT_ERR_OOM, "host allocation failed");
+    memset(static_cast<void*>(b), 0, sizeof *b);
+    b->dev = d;
+    b->bytes = bytes;
+    b->owned = true;
+    if (bytes) {
+        hipError_t e = hipMalloc(&b->dptr, bytes);
+        if (e != hipSuccess) {
+            delete b;
+            return fail(PT_ERR_OOM, "hipMalloc(%zu) failed: %s (used %llu bytes)", bytes, hipGetErrorString(e),
+                        (unsigned long long)d->used);
+        }
+    }
+    d->used += bytes;
+    d->peak = std::max(d->peak, d->used);
+    d->live_buffers++;
+    *out = b;
+    return PT_OK;
+}
+
+extern "C" int pt_buffer_wrap(pt_device_t d, void* device_ptr, size_t bytes, pt_buffer_t* out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!device_ptr && bytes) return fail(PT_ERR_INVALID, "null device pointer");
+    pt_buffer_s* b = new (std::nothrow) pt_buffer_s();
+    if (!b) return fail(PT_ERR_OOM, "host allocation failed");
+    memset(static_cast<void*>(b), 0, sizeof *b);
+    b->dev = d;
+    b->dptr = device_ptr;
+    b->bytes = bytes;
+    b->owned = false;
+    d->live_buffers++;
+    *out = b;
+    return PT_OK;
+}
+
+extern "C" int pt_buffer_free(pt_buffer_t b)
+{
+    if (!b) return fail(PT_ERR_INVALID, "null buffer handle");
+    pt_device_s* d = b->dev;
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (d->pending.active && (d->pending.tris == b || d->pending.mats == b || d->pending.fb == b)) rc = flush_pending(d);
+    hipStreamSynchronize(d->stream);  // nothing in flight may still touch it
+    if (d->prep_src == b) d->prep_src = nullptr;
+    if (b->staging) hipHostFree(b->staging);
+    if (b->owned) {
+        if (b->dptr) hipFree(b->dptr);
+        d->used -= b->bytes;
+    }
+    d->live_buffers--;
+    delete b;
+    return rc;
+}
+
+extern "C" size_t pt_buffer_size(pt_buffer_t b) { return b ? b->bytes : 0; }
+extern "C" void* pt_buffer_device_ptr(pt_buffer_t b) { return b ? b->dptr : nullptr; }
+
+static int check_range(const pt_buffer_s* b, size_t off, size_t bytes, const char* what)
+{
+    if (!b) return fail(PT_ERR_INVALID, "null buffer handle (%s)", what);
+    if (off > b->bytes || bytes > b->bytes - off)
+        return fail(PT_ERR_RANGE, "%s: range [%zu, +%zu) outside buffer of %zu bytes", what, off, bytes, b->bytes);
+    return PT_OK;
+}
+
+static int event_begin(pt_device_s* d, pt_event_s* ev)
+{
+    if (!ev) return PT_OK;
+    if (ev->dev != d) return fail(PT_ERR_INVALID, "event belongs to another device");
+    HIP_TRY(hipEventRecord(ev->start, d->stream));
+    return PT_OK;
+}
+
+static int event_end(pt_device_s* d, pt_event_s* ev)
+{
+    if (!ev) return PT_OK;
+    HIP_TRY(hipEventRecord(ev->stop, d->stream));
+    ev->recorded = true;
+    return PT_OK;
+}
+
+extern "C" int pt_buffer_write(pt_buffer_t dst, const void* host_src, size_t bytes, size_t dst_offset, pt_event_t ev)
+{
+    int rc = check_range(dst, dst_offset, bytes, "pt_buffer_write");
+    if (rc) return rc;
+    pt_device_s* d = dst->dev;
+    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if (!host_src && bytes) return fail(PT_ERR_INVALID, "null host pointer");
+    if ((rc = event_begin(d, ev))) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync((char*)dst->dptr + dst_offset, host_src, bytes, hipMemcpyHostToDevice, d->stream));
+    dst->version++;
+    return event_end(d, ev);
+}
+
+extern "C" int pt_buffer_read(pt_buffer_t src, void* host_dst, size_t bytes, size_t src_offset, pt_event_t ev)
+{
+    int rc = check_range(src, src_offset, bytes, "pt_buffer_read");
+    if (rc) return rc;
+    pt_device_s* d = src->dev;
+    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if (!host_dst && bytes) return fail(PT_ERR_INVALID, "null host pointer");
+    if ((rc = event_begin(d, ev))) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, (const char*)src->dptr + src_offset, bytes, hipMemcpyDeviceToHost, d->stream));
+    return event_end(d, ev);
+}
+
+extern "C" int pt_buffer_copy(pt_buffer_t dst, pt_buffer_t src, size_t bytes, size_t dst_offset, size_t src_offset,
+                              pt_event_t ev)
+{
+    int rc = check_range(dst, dst_offset, bytes, "pt_buffer_copy(dst)");
+    if (rc) return rc;
+    if ((rc = check_range(src, src_offset, bytes, "pt_buffer_copy(src)"))) return rc;
+    if (dst->dev != src->dev) return fail(PT_ERR_INVALID, "buffers belong to different devices");
+    pt_device_s* d = dst->dev;
+    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if ((rc = event_begin(d, ev))) return rc;
+    if (bytes)
+        HIP_TRY(hipMemcpyAsync((char*)dst->dptr + dst_offset, (const char*)src->dptr + src_offset, bytes,
+                               hipMemcpyDeviceToDevice, d->stream));
+    dst->version++;
+    return event_end(d, ev);
+}
+
+extern "C" void* pt_buffer_map(pt_buffer_t b, size_t bytes, int blocking)
+{
+    if (!b) { fail(PT_ERR_INVALID, "null buffer handle"); return nullptr; }
+    pt_device_s* d = b->dev;
+    if (use_device(d) || flush_pending(d)) return nullptr;
+    if (bytes == (size_t)-1) bytes = b->bytes;
+    if (check_range(b, 0, bytes, "pt_buffer_map")) return nullptr;
+    if (b->mapped) { fail(PT_ERR_INVALID, "buffer is already mapped"); return nullptr; }
+    size_t need = std::max<size_t>(bytes, 1);
+    if (b->staging_bytes < need) {
+        if (b->staging) {
+            hipStreamSynchronize(d->stream);
+            hipHostFree(b->staging);
+            b->staging = nullptr;
+            b->staging_bytes = 0;
+        }
+        hipError_t e = hipHostMalloc(&b->staging, need, hipHostMallocDefault);
+        if (e != hipSuccess) { fail(PT_ERR_OOM, "hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return nullptr; }
+        b->staging_bytes = need;
+    }
+    if (bytes) {
+        hipError_t e = hipMemcpyAsync(b->staging, b->dptr, bytes, hipMemcpyDeviceToHost, d->stream);
+        if (e != hipSuccess) { fail(PT_ERR_HIP, "map copy failed: %s", hipGetErrorString(e)); return nullptr; }
+    }
+    if (blocking) {
+        hipError_t e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) { fail(PT_ERR_HIP, "map sync failed: %s", hipGetErrorString(e)); return nullptr; }
+    }
+    b->mapped = true;
+    return b->staging;
+}
+
+extern "C" int pt_buffer_unmap(pt_buffer_t b, void* host_ptr)
+{
+    if (!b) return fail(PT_ERR_INVALID, "null buffer handle");
+    if (!b->mapped || host_ptr != b->staging) return fail(PT_ERR_INVALID, "pointer was not returned by pt_buffer_map of this buffer");
+    pt_device_s* d = b->dev;
+    int rc;
+    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    size_t bytes = std::min(b->staging_bytes, b->bytes);
+    if (bytes) HIP_TRY(hipMemcpyAsync(b->dptr, b->staging, bytes, hipMemcpyHostToDevice, d->stream));
+    b->mapped = false;
+    b->version++;
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// events
+// ------------------------------------------------------------------------------------------
+extern "C" int pt_event_create(pt_device_t d, pt_event_t* out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    int rc = use_device(d);
+    if (rc) return rc;
+    pt_event_s* e = new (std::nothrow) pt_event_s();
+    if (!e) return fail(PT_ERR_OOM, "host allocation failed");
+    e->dev = d;
+    e->recorded = false;
+    if (hipEventCreate(&e->start) != hipSuccess || hipEventCreate(&e->stop) != hipSuccess) {
+        delete e;
+        return fail(PT_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = e;
+    return PT_OK;
+}
+
+extern "C" int pt_event_destroy(pt_event_t e)
+{
+    if (!e) return fail(PT_ERR_INVALID, "null event handle");
+    hipEventDestroy(e->start);
+    hipEventDestroy(e->stop);
+    delete e;
+    return PT_OK;
+}
+
+extern "C" int pt_event_wait(pt_event_t e)
+{
+    if (!e) return fail(PT_ERR_INVALID, "null event handle");
+    if (!e->recorded) return PT_OK;
+    int rc = use_device(e->dev);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(e->stop));
+    return PT_OK;
+}
+
+extern "C" int pt_event_is_complete(pt_event_t e)
+{
+    if (!e) { fail(PT_ERR_INVALID, "null event handle"); return -1; }
+    if (!e->recorded) return 1;
+    if (use_device(e->dev)) return -1;
+    hipError_t s = hipEventQuery(e->stop);
+    if (s == hipSuccess) return 1;
+    if (s == hipErrorNotReady) return 0;
+    fail(PT_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(s));
+    return -1;
+}
+
+extern "C" int pt_event_elapsed_ns(pt_event_t e, uint64_t* ns_out)
+{
+    if (!e || !ns_out) return fail(PT_ERR_INVALID, "null argument");
+    if (!e->recorded) return fail(PT_ERR_INVALID, "event was never recorded");
+    int rc = use_device(e->dev);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(e->stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->start, e->stop));
+    *ns_out = (uint64_t)((double)ms * 1.0e6);
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused renderer
+// ------------------------------------------------------------------------------------------
+extern "C" int pt_local_rows(int height, int stripe_rows, int n_ranks, int rank)
+{
+    if (height < 0 || stripe_rows < 1 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return -1;
+    long long rows = 0;
+    long long period = (long long)stripe_rows * n_ranks;
+    long long full = height / period;
+    rows = full * stripe_rows;
+    long long rem = height - full * period;          // rows of the last, partial period
+    long long start = (long long)rank * stripe_rows;  // this rank's stripe inside it
+    if (rem > start) rows += std::min<long long>(stripe_rows, rem - start);
+    return (int)rows;
+}
+
+static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
+{
+    if (d->prep_capacity < (size_t)ntri) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        if (d->prep) hipFree(d->prep);
+        d->prep = nullptr;
+        d->prep_capacity = 0;
+        size_t cap = std::max<size_t>((size_t)ntri, 64);
+        hipError_t e = hipMalloc(&d->prep, cap * sizeof(PtPrepTriangle));
+        if (e != hipSuccess) return fail(PT_ERR_OOM, "scene workspace allocation failed: %s", hipGetErrorString(e));
+        d->prep_capacity = cap;
+        d->prep_src = nullptr;
+    }
+    // wrapped (caller-owned) memory can change behind our back: always re-prepare it
+    if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned) return PT_OK;
+    HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->stream));
+    d->prep_src = tris;
+    d->prep_version = tris->version;
+    d->prep_ntri = ntri;
+    return PT_OK;
+}
+
+// pixel_count: 0 = all local pixels; otherwise the first pixel_count local pixels (n_ranks must be 1)
+static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_buffer_s* fb,
+                           const pt_render_params& rp, uint32_t pixel_count, pt_buffer_s* stats, pt_event_s* ev)
+{
+    if (!tris || !mats || !fb) return fail(PT_ERR_INVALID, "null buffer handle");
+    if (tris->dev != d || mats->dev != d || fb->dev != d || (stats && stats->dev != d))
+        return fail(PT_ERR_INVALID, "buffer belongs to another device");
+    if (rp.width < 1 || rp.height < 1 || rp.frame_begin < 0 || rp.frame_count < 0 || rp.max_bounces < 1 ||
+        rp.num_triangles < 0 || rp.num_materials < 1 || rp.stripe_rows < 1 || rp.n_ranks < 1 || rp.rank < 0 ||
+        rp.rank >= rp.n_ranks)
+        return fail(PT_ERR_INVALID, "invalid render parameters");
+    for (int i = 0; i < 6; ++i)
+        if (rp.reserved[i] != 0) return fail(PT_ERR_INVALID, "reserved fields must be zero");
+    if ((long long)rp.width * rp.height > 0x7fffffffLL) return fail(PT_ERR_INVALID, "image too large");
+    if ((long long)rp.frame_begin + rp.frame_count > 0x7fffffffLL) return fail(PT_ERR_INVALID, "frame index overflow");
+    int rows = pt_local_rows(rp.height, rp.stripe_rows, rp.n_ranks, rp.rank);
+    uint64_t npix64 = (uint64_t)rows * (uint64_t)rp.width;
+    if (pixel_count) {
+        if (rp.n_ranks != 1) return fail(PT_ERR_INVALID, "pixel_count needs n_ranks == 1");
+        npix64 = std::min<uint64_t>(npix64, pixel_count);
+    }
+    uint32_t npix = (uint32_t)npix64;
+    if ((size_t)rp.num_triangles * sizeof(PtRawTriangle) > tris->bytes)
+        return fail(PT_ERR_RANGE, "triangle buffer holds %zu bytes, %d triangles need %zu", tris->bytes, rp.num_triangles,
+                    (size_t)rp.num_triangles * sizeof(PtRawTriangle));
+    if ((size_t)rp.num_materials * sizeof(PtRawMaterial) > mats->bytes)
+        return fail(PT_ERR_RANGE, "material buffer holds %zu bytes, %d materials need %zu", mats->bytes, rp.num_materials,
+                    (size_t)rp.num_materials * sizeof(PtRawMaterial));
+    if ((size_t)npix * sizeof(float4) > fb->bytes)
+        return fail(PT_ERR_RANGE, "framebuffer holds %zu bytes, %u pixels need %zu", fb->bytes, npix, (size_t)npix * sizeof(float4));
+    if (stats && stats->bytes < PT_STAT_WORDS * sizeof(uint64_t)) return fail(PT_ERR_RANGE, "stats buffer too small");
+
+    int rc = event_begin(d, ev);
+    if (rc) return rc;
+    if (npix == 0 || rp.frame_count == 0) return event_end(d, ev);
+    if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
+
+    // frames per chunk: radiance staging is 16 B x pixels x frames
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 16);
+    budget = std::min<uint64_t>(budget, (uint64_t)free_b / 2 + d->rad_bytes);
+    int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 16)));
+    if (d->opt_chunk > 0) chunk = (int)std::min<int64_t>(chunk, d->opt_chunk);
+    int nchunks = (rp.frame_count + chunk - 1) / chunk;
+    if (nchunks > PT_MAX_CHUNKS) {
+        chunk = (rp.frame_count + PT_MAX_CHUNKS - 1) / PT_MAX_CHUNKS;
+        nchunks = (rp.frame_count + chunk - 1) / chunk;
+        if ((uint64_t)chunk * npix * 16 > budget) return fail(PT_ERR_OOM, "not enough device memory for radiance staging");
+    }
+    size_t need = (size_t)chunk * npix * sizeof(float4);
+    if (d->rad_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        if (d->rad) hipFree(d->rad);
+        d->rad = nullptr;
+        d->rad_bytes = 0;
+        hipError_t e = hipMalloc(&d->rad, need);
+        if (e != hipSuccess) return fail(PT_ERR_OOM, "radiance staging allocation (%zu bytes) failed: %s", need, hipGetErrorString(e));
+        d->rad_bytes = need;
+    }
+    HIP_TRY(hipMemsetAsync(d->counters, 0, (size_t)nchunks * sizeof(unsigned int), d->stream));
+
+    const uint32_t bpf = (npix + PT_TRACE_BATCH - 1) / PT_TRACE_BATCH;
+    for (int c = 0; c < nchunks; ++c) {
+        int f0 = c * chunk;
+        int nf = std::min(chunk, rp.frame_count - f0);
+        uint64_t total_batches = (uint64_t)bpf * nf;
+        if (total_batches > 0xffffffffull) return fail(PT_ERR_INVALID, "chunk too large");
+        PtTraceParams tp;
+        memset(&tp, 0, sizeof tp);
+        tp.tris = d->prep;
+        tp.mats = (const PtRawMaterial*)mats->dptr;
+        tp.rad = d->rad;
+        tp.batch_counter = d->counters + c;
+        tp.stats = stats ? (unsigned long long*)stats->dptr : nullptr;
+        tp.width = rp.width;
+        tp.height = rp.height;
+        tp.frame_begin = rp.frame_begin + f0;
+        tp.frame_count = nf;
+        tp.max_bounces = rp.max_bounces;
+        tp.ntri = rp.num_triangles;
+        tp.nmat = rp.num_materials;
+        tp.stripe_rows = rp.stripe_rows;
+        tp.n_ranks = rp.n_ranks;
+        tp.rank = rp.rank;
+        tp.npix_local = npix;
+        tp.batches_per_frame = bpf;
+        tp.total_batches = (uint32_t)total_batches;
+        // persistent grid: fill the chip, but never more waves than batches
+        uint64_t waves_needed = total_batches;
+        int blocks = d->prop.multiProcessorCount * d->blocks_per_cu;
+        uint64_t blocks_needed = (waves_needed + (PT_TRACE_THREADS / 64) - 1) / (PT_TRACE_THREADS / 64);
+        if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
+        hipEvent_t pstop;
+        if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
+        HIP_TRY(ptk_trace(tp, blocks, d->stream));
+        if ((rc = prof_end(d, pstop))) return rc;
+        PtFoldParams fp;
+        fp.rad = d->rad;
+        fp.fb = (float4*)fb->dptr;
+        fp.npix_local = npix;
+        fp.frame_begin = rp.frame_begin + f0;
+        fp.frame_count = nf;
+        if ((rc = prof_begin(d, PT_PROF_FOLD, &pstop))) return rc;
+        HIP_TRY(ptk_fold(fp, d->stream));
+        if ((rc = prof_end(d, pstop))) return rc;
+    }
+    fb->version++;
+    if (stats) stats->version++;
+    return event_end(d, ev);
+}
+
+static int flush_pending(pt_device_s* d)
+{
+    if (!d->pending.active) return PT_OK;
+    PendingFrames p = d->pending;
+    d->pending.active = false;
+    pt_render_params rp;
+    memset(&rp, 0, sizeof rp);
+    rp.width = p.width;
+    rp.height = p.height;
+    rp.frame_begin = p.z_begin;
+    rp.frame_count = p.z_count;
+    rp.max_bounces = 16;    // BOUNCES       GenerateColors.cl:5
+    rp.num_triangles = 36;  // NUM_TRIANGLES GenerateColors.cl:6
+    rp.num_materials = (int)std::min<size_t>(p.mats->bytes / sizeof(PtRawMaterial), 0x7fffffff);
+    rp.stripe_rows = 1;
+    rp.n_ranks = 1;
+    rp.rank = 0;
+    return render_internal(d, p.tris, p.mats, p.fb, rp, p.pixel_count, nullptr, nullptr);
+}
+
+extern "C" int pt_render_frames(pt_device_t d, pt_buffer_t triangles, pt_buffer_t materials, pt_buffer_t framebuffer,
+                                const pt_render_params* params, pt_buffer_t stats, pt_event_t ev)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!params) return fail(PT_ERR_INVALID, "params == NULL");
+    if ((rc = flush_pending(d))) return rc;
+    return render_internal(d, triangles, materials, framebuffer, *params, 0, stats, ev);
+}
+
+extern "C" int pt_assemble_stripes(pt_device_t d, pt_buffer_t gathered, pt_buffer_t image, int width, int height,
+                                   int stripe_rows, int n_ranks, int slab_rows, pt_event_t ev)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!gathered || !image) return fail(PT_ERR_INVALID, "null buffer handle");
+    if (gathered->dev != d || image->dev != d) return fail(PT_ERR_INVALID, "buffer belongs to another device");
+    if (width < 1 || height < 1 || stripe_rows < 1 || n_ranks < 1 || slab_rows < 0) return fail(PT_ERR_INVALID, "invalid geometry");
+    for (int r = 0; r < n_ranks; ++r)
+        if (pt_local_rows(height, stripe_rows, n_ranks, r) > slab_rows) return fail(PT_ERR_INVALID, "slab_rows too small for rank %d", r);
+    if ((size_t)n_ranks * slab_rows * width * sizeof(float4) > gathered->bytes) return fail(PT_ERR_RANGE, "gathered buffer too small");
+    if ((size_t)width * height * sizeof(float4) > image->bytes) return fail(PT_ERR_RANGE, "image buffer too small");
+    if ((rc = flush_pending(d)) || (rc = event_begin(d, ev))) return rc;
+    HIP_TRY(ptk_assemble_stripes((const float4*)gathered->dptr, (float4*)image->dptr, width, height, stripe_rows, n_ranks,
+                                 slab_rows, d->stream));
+    image->version++;
+    return event_end(d, ev);
+}
+
+extern "C" int pt_tonemap_ppm(pt_device_t d, pt_buffer_t framebuffer, pt_buffer_t rgb_i32, size_t num_pixels, pt_event_t ev)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!framebuffer || !rgb_i32) return fail(PT_ERR_INVALID, "null buffer handle");
+    if (framebuffer->dev != d || rgb_i32->dev != d) return fail(PT_ERR_INVALID, "buffer belongs to another device");
+    if (num_pixels * sizeof(float4) > framebuffer->bytes) return fail(PT_ERR_RANGE, "framebuffer too small");
+    if (num_pixels * 3 * sizeof(int32_t) > rgb_i32->bytes) return fail(PT_ERR_RANGE, "rgb buffer too small");
+    if ((rc = flush_pending(d)) || (rc = event_begin(d, ev))) return rc;
+    HIP_TRY(ptk_tonemap_ppm((const float4*)framebuffer->dptr, (int32_t*)rgb_i32->dptr, num_pixels, d->stream));
+    rgb_i32->version++;
+    return event_end(d, ev);
+}
+
+extern "C" int pt_profile_enable(pt_device_t d, int on)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    d->prof_on = on != 0;
+    return PT_OK;
+}
+
+extern "C" int pt_profile_reset(pt_device_t d)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (int k = 0; k < PT_PROF_KINDS; ++k) d->prof_used[k] = 0;
+    return PT_OK;
+}
+
+extern "C" int pt_profile_query(pt_device_t d, int kind, double* total_ms, uint64_t* launches)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (kind < 0 || kind >= PT_PROF_KINDS || !total_ms || !launches) return fail(PT_ERR_INVALID, "bad profile query");
+    if ((rc = flush_pending(d))) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < d->prof_used[kind]; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, d->prof_pairs[kind][i].first, d->prof_pairs[kind][i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = d->prof_used[kind];
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel registry + generic launcher
+// ------------------------------------------------------------------------------------------
+static const char* base_name(const char* path)
+{
+    const char* b = path;
+    for (const char* p = path; *p; ++p)
+        if (*p == '/' || *p == '\\') b = p + 1;
+    return b;
+}
+
+extern "C" int pt_kernel_get(pt_device_t d, const char* file_name, const char* func_name, pt_kernel_t* out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    if (!d || !file_name || !func_name) return fail(PT_ERR_INVALID, "null argument");
+    std::string base = base_name(file_name);
+    size_t dot = base.rfind('.');
+    if (dot != std::string::npos) base.erase(dot);  // SELECT_KERNELPATH1 appends no extension; accept either
+    for (int i = 0; i < KERNEL_COUNT; ++i)
+        if (base == d->kernels[i].file && strcmp(func_name, d->kernels[i].func) == 0) {
+            *out = &d->kernels[i];
+            return PT_OK;
+        }
+    return fail(PT_ERR_NOT_FOUND, "no native kernel registered for (%s, %s)", file_name, func_name);
+}
+
+static int launch_generate_colors(pt_device_s* d, const pt_launch_arg* a, int nargs, long long n, pt_event_s* ev, float* ms_out)
+{
+    // __kernel void GenerateColors(tBuffer, matBuffer, gDst, const int4 cRes)  GenerateColors.cl:302-303
+    if (nargs != 4 || !a[0].is_buffer || !a[1].is_buffer || !a[2].is_buffer || a[3].is_buffer || a[3].size != 16)
+        return fail(PT_ERR_ARGS, "GenerateColors expects (buffer, buffer, buffer, int4)");
+    pt_buffer_s *t = a[0].buffer, *m = a[1].buffer, *fb = a[2].buffer;
+    if (!t || !m || !fb) return fail(PT_ERR_ARGS, "GenerateColors: null buffer argument");
+    int32_t c[4];
+    memcpy(c, a[3].data, 16);  // {W, H, frame, unused}: test/RaytraceTest.cpp:252-253
+    if (c[0] < 1 || c[1] < 1 || c[2] < 0) return fail(PT_ERR_ARGS, "GenerateColors: invalid cRes {%d,%d,%d}", c[0], c[1], c[2]);
+    long long npix = std::min<long long>(n, (long long)c[0] * c[1]);  // the kernel guards gid < W*H
+    if (npix <= 0) return PT_OK;
+    if (npix > 0xffffffffLL) return fail(PT_ERR_ARGS, "too many work-items");
+    if (m->bytes < sizeof(PtRawMaterial)) return fail(PT_ERR_RANGE, "material buffer too small");
+
+    bool immediate = !d->opt_batch || ev || d->opt_profile;
+    PendingFrames& p = d->pending;
+    if (p.active && !(p.tris == t && p.mats == m && p.fb == fb && p.width == c[0] && p.height == c[1] &&
+                      p.pixel_count == (uint32_t)npix && p.z_begin + p.z_count == c[2] && !immediate)) {
+        int rc = flush_pending(d);
+        if (rc) return rc;
+    }
+    if (!immediate) {
+        // validate now what flush would reject later, so errors surface at the launch
+        if ((size_t)36 * sizeof(PtRawTriangle) > t->bytes) return fail(PT_ERR_RANGE, "triangle buffer smaller than 36 triangles");
+        if ((size_t)npix * sizeof(float4) > fb->bytes) return fail(PT_ERR_RANGE, "framebuffer smaller than the launch");
+        if (t->dev != d || m->dev != d || fb->dev != d) return fail(PT_ERR_INVALID, "buffer belongs to another device");
+        if (p.active) {
+            p.z_count++;
+        } else {
+            p.active = true;
+            p.tris = t; p.mats = m; p.fb = fb;
+            p.width = c[0]; p.height = c[1];
+            p.z_begin = c[2]; p.z_count = 1;
+            p.pixel_count = (uint32_t)npix;
+        }
+        if (ms_out) *ms_out = 0.f;
+        return PT_OK;
+    }
+    pt_render_params rp;
+    memset(&rp, 0, sizeof rp);
+    rp.width = c[0]; rp.height = c[1];
+    rp.frame_begin = c[2]; rp.frame_count = 1;
+    rp.max_bounces = 16; rp.num_triangles = 36;
+    rp.num_materials = (int)std::min<size_t>(m->bytes / sizeof(PtRawMaterial), 0x7fffffff);
+    rp.stripe_rows = 1; rp.n_ranks = 1; rp.rank = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (d->opt_profile) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, d->stream));
+    }
+    int rc = render_internal(d, t, m, fb, rp, (uint32_t)npix, nullptr, ev);
+    if (d->opt_profile) {
+        float ms = 0.f;
+        if (!rc) {
+            hipEventRecord(e1, d->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        if (ms_out) *ms_out = ms;
+    } else if (ms_out) {
+        *ms_out = 0.f;
+    }
+    return rc;
+}
+
+static int launch_fill(pt_device_s* d, const pt_launch_arg* a, int nargs, long long n, pt_event_s* ev)
+{
+    // FillKernel(int* dst, int value): the shim smoke kernel (test/main.cpp:128-151 uses one from a
+    // TestKernel.cl the reference does not ship)
+    if (nargs != 2 || !a[0].is_buffer || a[1].is_buffer || a[1].size != 4) return fail(PT_ERR_ARGS, "FillKernel expects (buffer, int)");
+    pt_buffer_s* b = a[0].buffer;
+    if (!b || b->dev != d) return fail(PT_ERR_ARGS, "FillKernel: bad buffer");
+    int32_t v;
+    memcpy(&v, a[1].data, 4);
+    long long cnt = std::min<long long>(n, (long long)(b->bytes / 4));
+    int rc = flush_pending(d);
+    if (rc || (rc = event_begin(d, ev))) return rc;
+    HIP_TRY(ptk_fill_i32((int32_t*)b->dptr, v, (int)std::min<long long>(cnt, 0x7fffffff), d->stream));
+    b->version++;
+    return event_end(d, ev);
+}
+
+extern "C" int pt_launch_2d(pt_device_t d, pt_kernel_t k, const pt_launch_arg* args, int nargs, int ntx, int nty, int lx,
+                            int ly, pt_event_t ev, float* ms_out)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!k) return fail(PT_ERR_NOT_FOUND, "null kernel (Device::getKernel returned 0)");
+    if (k < d->kernels || k >= d->kernels + KERNEL_COUNT) return fail(PT_ERR_INVALID, "kernel belongs to another device");
+    if (nargs < 0 || nargs > PT_MAX_ARG_COUNT || (nargs && !args)) return fail(PT_ERR_ARGS, "bad argument list");
+    for (int i = 0; i < nargs; ++i)
+        if (!args[i].is_buffer && args[i].size > PT_MAX_ARG_SIZE) return fail(PT_ERR_ARGS, "constant %d larger than %d bytes", i, PT_MAX_ARG_SIZE);
+    if (ntx < 0 || nty < 0 || lx < 1 || ly < 1) return fail(PT_ERR_ARGS, "bad launch geometry");
+    if (ev && ev->dev != d) return fail(PT_ERR_INVALID, "event belongs to another device");
+    long long n = (long long)ntx * nty;  // work-items the caller asked for (kernels guard the rounded-up tail)
+    if (ms_out) *ms_out = 0.f;
+    switch (k->id) {
+    case KERNEL_GENERATE_COLORS: return launch_generate_colors(d, args, nargs, n, ev, ms_out);
+    case KERNEL_FILL: return launch_fill(d, args, nargs, n, ev);
+    default: return fail(PT_ERR_NOT_FOUND, "unknown kernel id");
+    }
+}

@@ -1,0 +1,122 @@
+"""Multi-GPU sharding of the framebuffer: one process per GPU, image stripes, one gather.
+
+The path shards by independent units: every (pixel, frame) sample depends only
+on its GLOBAL pixel id and frame (GenerateColors.cl:305-312), so ranks share nothing while
+rendering.  The only exchange is the final image assembly: rank k sends its slab of rows to
+rank 0 (``torch.distributed.gather``; backend "nccl" = RCCL over xGMI -- 7 peers write into the
+root over 7 distinct links, so no ring), and rank 0 scatters the slabs into image order with
+the ``pt_assemble_stripes`` HIP kernel.
+
+Rows are dealt in stripes of ``stripe_rows`` rows, round-robin over ranks, because path length
+(hence cost) varies with image height: ceiling rows are cheap, floor/box rows are deep.
+
+torch is plumbing here (device memory, streams, the collective); import it BEFORE the shim so
+both bind to the same HIP runtime.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import adl, shim
+from .render import Renderer
+
+
+class StripePlan:
+    """Which image rows each rank owns.  Pure index math; mirrors pt_local_rows() and the
+    row mapping of pt_trace_kernel / pt_assemble_kernel."""
+
+    def __init__(self, height: int, stripe_rows: int, world: int):
+        if height < 1 or stripe_rows < 1 or world < 1:
+            raise ValueError("invalid stripe plan")
+        self.height, self.stripe_rows, self.world = int(height), int(stripe_rows), int(world)
+
+    def global_rows(self, rank: int) -> np.ndarray:
+        rows = np.arange(self.height)
+        return rows[(rows // self.stripe_rows) % self.world == rank]
+
+    def local_rows(self, rank: int) -> int:
+        period = self.stripe_rows * self.world
+        full, rem = divmod(self.height, period)
+        start = rank * self.stripe_rows
+        return full * self.stripe_rows + (min(self.stripe_rows, rem - start) if rem > start else 0)
+
+    @property
+    def slab_rows(self) -> int:
+        """Rows per gathered slab (the largest share; smaller shares are zero-padded)."""
+        return max(self.local_rows(r) for r in range(self.world))
+
+
+def gather_slabs(local_slab: torch.Tensor, world: int, rank: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gather equally-shaped per-rank slabs to ``dst``; returns [world, *slab.shape] there, else None.
+
+    Works with any initialised backend (nccl on GPUs; gloo in the CPU rehearsal tests)."""
+    if world == 1:
+        return local_slab.unsqueeze(0)
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
+        dist.gather(local_slab, [out[i] for i in range(world)], dst=dst, group=group)
+        return out
+    dist.gather(local_slab, None, dst=dst, group=group)
+    return None
+
+
+class StripeImage:
+    """One rank's renderer + the gather/assemble step.  The local framebuffer is a torch CUDA
+    tensor (so the collective moves it with no staging copy) wrapped by the shim."""
+
+    def __init__(self, dev: adl.Device, triangles, materials, width: int, height: int, *, world: int = 1, rank: int = 0,
+                 stripe_rows: int = 16, want_stats: bool = False):
+        self.dev, self.world, self.rank = dev, int(world), int(rank)
+        self.width, self.height = int(width), int(height)
+        self.plan = StripePlan(height, stripe_rows, world)
+        self.cuda = torch.device("cuda", torch.cuda.current_device())
+        # all of this rank's device work goes onto torch's current stream
+        shim.check(shim.load().pt_device_set_stream(dev._h, torch.cuda.current_stream().cuda_stream))
+        self.local = torch.zeros((self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
+        self.renderer = Renderer(dev, triangles, materials, width, height, n_ranks=world, rank=rank,
+                                 stripe_rows=stripe_rows, fb_device_ptr=self.local.data_ptr(), want_stats=want_stats)
+        assert self.renderer.local_rows == self.plan.local_rows(rank)
+        self.image = None
+        self._gbuf = self._ibuf = None
+        if rank == 0 and world > 1:
+            self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=self.cuda)
+
+    def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> None:
+        self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces)
+
+    def gather(self) -> Optional[torch.Tensor]:
+        """Assemble the full image on rank 0 (returns it there; None elsewhere)."""
+        if self.world == 1:
+            self.image = self.local[: self.height]
+            return self.image
+        slabs = gather_slabs(self.local, self.world, self.rank)
+        if self.rank != 0:
+            return None
+        lib = shim.load()
+        g = adl.Buffer(dtype=adl.float4)
+        i = adl.Buffer(dtype=adl.float4)
+        g.setRawPtr(self.dev, slabs.data_ptr(), slabs.numel() // 4)
+        i.setRawPtr(self.dev, self.image.data_ptr(), self.image.numel() // 4)
+        try:
+            shim.check(lib.pt_assemble_stripes(self.dev._h, g._h, i._h, self.width, self.height, self.plan.stripe_rows,
+                                               self.world, self.plan.slab_rows, None))
+        finally:
+            # buffer release synchronises the stream, so `slabs` may be dropped afterwards
+            g.release()
+            i.release()
+        return self.image
+
+    def reset_stats(self) -> None:
+        if self.renderer.stats is not None:
+            self.renderer.stats.write(np.zeros(shim.PT_STAT_WORDS, np.uint64), shim.PT_STAT_WORDS)
+            self.dev.waitForCompletion()
+
+    def read_stats(self) -> dict:
+        return self.renderer.read_stats()
+
+    def release(self) -> None:
+        self.renderer.release()

@@ -168,12 +168,15 @@ def make_soup(ntri: int = 1_000_000, seed: int = 20261004, path: str | None = No
 
 
 def f2c(v: np.ndarray) -> np.ndarray:
-    """``f2c(sqrtf(v))`` of the reference's PPM writer (RaytraceTest.cpp:78-83, 280-285)."""
-    a = np.sqrt(np.asarray(v, np.float32)) * np.float32(255)
+    """``f2c(sqrtf(v))`` of the reference's PPM writer (RaytraceTest.cpp:78-83, 280-285):
+    ``a *= 255; min((int)a, 255)`` with the x86 float->int conversion (NaN / out-of-range give
+    INT_MIN).  Returned as int32: the reference prints its u32 with %d."""
     with np.errstate(invalid="ignore"):
-        b = np.where(np.isnan(a), np.float32(-2147483648.0), a)  # (int)NaN is INT_MIN on x86
-        b = np.clip(b, -2147483648.0, 2147483520.0).astype(np.int32)
-    return np.minimum(b, 255)  # int32: the reference prints its u32 with %d
+        a = np.sqrt(np.asarray(v, np.float32)) * np.float32(255)
+        bad = np.isnan(a) | (a >= np.float32(2147483648.0)) | (a < np.float32(-2147483648.0))
+        i = np.where(bad, 0.0, np.trunc(a)).astype(np.int64)
+    i = np.where(bad, -2147483648, i)
+    return np.minimum(i, 255).astype(np.int32)
 
 
 def write_ppm(path: str, fb: np.ndarray, W: int, H: int) -> None:
