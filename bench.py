@@ -44,12 +44,35 @@ def flops_per_ray_from_tallies(st: dict) -> float:
     return (tri + shade) / rays
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(tris, mats, depth, target_seconds=12.0):
     """Time the CPU oracle (all host cores) on a bounded 256x256 sample of the workload."""
     from oracle import ptoracle
 
     ptoracle.build()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     W = H = 256
     t0 = time.perf_counter()
     ptoracle.render(tris, mats, W, H, 2, max_bounces=depth, nthreads=cores)  # warm-up + calibration
