@@ -1,0 +1,77 @@
+"""Host logic that needs no GPU: scene ingestion, soup generator, PPM output, stripe index math."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oclpathtracer_amd import scene
+
+
+def test_parse_rejects_truncated_and_bad_indices(tmp_path):
+    blob = open(scene.DEFAULT_SCENE, "rb").read()
+    for cut in (0, 3, 10, 100, len(blob) - 1):
+        with pytest.raises(ValueError):
+            scene.parse_meshes(blob[:cut])
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, 12, 99)  # first face index of mesh 0 out of range
+    with pytest.raises(ValueError):
+        scene.parse_meshes(bytes(bad))
+    assert scene.parse_meshes(struct.pack("<i", 0)) == []
+    p = tmp_path / "empty.bin"
+    p.write_bytes(struct.pack("<i", 0))
+    t, m = scene.load_model(str(p))
+    assert len(t) == 0 and len(m) == 0
+
+
+def test_records_are_64_bytes_and_zero_padded():
+    t, m = scene.load_model()
+    assert t.dtype.itemsize == 64 and m.dtype.itemsize == 64
+    assert not t["pad"].any() and not m["pad"].any()
+    assert np.all(m["roughness"][m["type"] == scene.DIFFUSE] == 0)  # reference leaves it uninitialised
+
+
+def test_soup_is_deterministic_and_well_formed():
+    a_t, a_m = scene.make_soup(5000)
+    b_t, b_m = scene.make_soup(5000)
+    assert a_t.tobytes() == b_t.tobytes() and a_m.tobytes() == b_m.tobytes()
+    c_t, _ = scene.make_soup(5000, seed=1)
+    assert a_t.tobytes() != c_t.tobytes()
+    base_t, base_m = scene.load_model()
+    assert a_t[:36].tobytes() == base_t.tobytes() and a_m[:18].tobytes() == base_m.tobytes()
+    assert len(a_t) == 5000 and len(a_m) == 18 + (5000 - 36 + 1) // 2
+    assert a_t["id"].max() == len(a_m) - 1 and a_t["id"][36] == 18
+    ext = a_t[36:]
+    assert np.all(np.abs(ext["p2"][:, :3] - ext["p1"][:, :3]) <= 0.02 + 1e-6)
+    assert ext["p1"][:, 0].min() >= -2.7 and ext["p1"][:, 1].max() <= 5.4 + 1e-6
+    assert np.all(a_m["type"][18:] == scene.DIFFUSE) and np.all(a_m["emissive"][18:, :3] == 0)
+    with pytest.raises(ValueError):
+        scene.make_soup(10)
+
+
+def test_f2c_and_ppm(tmp_path):
+    v = np.array([0, 0.25, 1, 4, np.nan, np.inf, -1.0, 1e-12], np.float32)
+    assert scene.f2c(v).tolist() == [0, 127, 255, 255, -2147483648, -2147483648, -2147483648, 0]
+    fb = np.zeros((4, 4), np.float32)
+    fb[:, :3] = [[0, 0.25, 1], [1, 1, 1], [0.04, 0.09, 0.16], [4, 0, 0]]
+    p = tmp_path / "o.ppm"
+    scene.write_ppm(str(p), fb, 2, 2)
+    assert p.read_text() == "P3\n2 2\n255\n0 127 255 255 255 255 51 76 102 255 0 0 "
+
+
+@pytest.mark.parametrize("H,stripe,world", [(64, 16, 1), (64, 16, 2), (64, 4, 8), (47, 5, 3), (40, 16, 8), (1, 1, 4), (1024, 16, 8)])
+def test_stripe_plan_partitions_rows(H, stripe, world):
+    torch = pytest.importorskip("torch")  # noqa: F841
+    from oclpathtracer_amd.distributed import StripePlan
+
+    plan = StripePlan(H, stripe, world)
+    seen = np.concatenate([plan.global_rows(r) for r in range(world)])
+    assert sorted(seen.tolist()) == list(range(H))
+    for r in range(world):
+        rows = plan.global_rows(r)
+        assert len(rows) == plan.local_rows(r)
+        # local row lr -> global row, the mapping pt_trace_kernel uses
+        lr = np.arange(len(rows))
+        g = ((lr // stripe) * world + r) * stripe + lr % stripe
+        assert np.array_equal(g, rows)
+    assert plan.slab_rows == max(plan.local_rows(r) for r in range(world))
