@@ -49,8 +49,12 @@ struct PtFoldParams {
     int32_t frame_begin, frame_count;
 };
 
-hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, hipStream_t s);
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, hipStream_t s);
+// det_bound_bits: device word receiving the bit pattern of max_i (|e1|_1 * |e2|_1)
+hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
+                              hipStream_t s);
+// det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, hipStream_t s);
+#define PT_DET_BOUND_MAX 2.0e19f
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);
 hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width, int height, int stripe_rows,
                                 int n_ranks, int slab_rows, hipStream_t s);

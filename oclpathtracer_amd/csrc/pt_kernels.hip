@@ -26,7 +26,8 @@ typedef const __attribute__((address_space(4))) float* pt_const_f32p;  // scalar
 // ------------------------------------------------------------------------------------------
 // scene preparation
 // ------------------------------------------------------------------------------------------
-__global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTriangle* __restrict__ out, int ntri)
+__global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTriangle* __restrict__ out, int ntri,
+                               unsigned int* __restrict__ det_bound_bits)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntri) return;
@@ -44,6 +45,11 @@ __global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTria
     t.n[0] = n.x; t.n[1] = n.y; t.n[2] = n.z;
     t.id = raw[i].id;
     out[i] = t;
+    // upper bound of |det| = |dot(e1, cross(dir, e2))| <= |e1| |e2| |dir| for this triangle, as
+    // L1 norms; non-negative floats order like their bit patterns, NaN/Inf sort above all finite
+    float b = (__builtin_fabsf(e1.x) + __builtin_fabsf(e1.y) + __builtin_fabsf(e1.z)) *
+              (__builtin_fabsf(e2.x) + __builtin_fabsf(e2.y) + __builtin_fabsf(e2.z));
+    atomicMax(det_bound_bits, __float_as_uint(b) & 0x7fffffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -76,8 +82,95 @@ PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& se
 }
 
 // ------------------------------------------------------------------------------------------
+// intersectTriangle (GenerateColors.cl:89-135) against a wave-uniform triangle record
+// ------------------------------------------------------------------------------------------
+struct PtTriRec { float p1x, p1y, p1z, e1x, e1y, e1z, e2x, e2y, e2z; };
+
+PTK_DEV PtTriRec pt_load_tri(pt_const_f32p T, int i)
+{
+    pt_const_f32p t = T + 16 * i;  // constant address space + uniform index -> s_load
+    PtTriRec r;
+    r.p1x = t[0]; r.p1y = t[1]; r.p1z = t[2];
+    r.e1x = t[3]; r.e1y = t[4]; r.e1z = t[5];
+    r.e2x = t[6]; r.e2y = t[7]; r.e2z = t[8];
+    return r;
+}
+
+// DET_BOUNDED: the host has verified |e1|*|e2| <= 2e19 for every triangle, so det <= 1e20 and
+// the short exact reciprocal applies to every front-facing triangle.
+#ifndef PT_FLAT_TRI
+#define PT_FLAT_TRI 1
+#endif
+
+#if PT_FLAT_TRI
+// Straight-line form: every lane evaluates the whole test and the five early returns of the
+// reference (:100,:109,:117,:125) become one predicate.  Values computed past a failed test are
+// never observed, so the accepted (t,u,v,index) are those of the branchy form bit for bit.  With
+// lane-level path regeneration the 64 rays of a wave are incoherent: the branchy form skipped
+// almost nothing (every stage had a live lane) yet paid ~20 SALU exec-mask/branch instructions
+// per triangle (rocprofv3: 757 SALU per 2100 VALU per wave-bounce).
+template <bool DET_BOUNDED>
+PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
+{
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    // (:100) returns when det < 1e-8f || -det > 1e-8f; the second clause implies the first
+    bool ok = !(det < 1e-8f);
+    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+    ok &= !(u < 0.0f) & !(u > 1.0f);  // :109
+    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
+    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
+    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
+    ok &= (tt > 0.0f) & (tt < tmax);  // :125
+    tmax = ok ? tt : tmax;
+    hu = ok ? u : hu;
+    hv = ok ? v : hv;
+    hidx = ok ? i : hidx;
+}
+#else
+template <bool DET_BOUNDED>
+PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
+{
+    // pvec = cross(dir, e2); det = dot(e1, pvec)   (:96-97)
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    if (det < 1e-8f || -det > 1e-8f) return;  // :100
+    // 1.0f / det (:105), correctly rounded; det >= 1e-8 here (or NaN)
+    float inv_det;
+    if (DET_BOUNDED) {
+        inv_det = pt_rcp_fast(det);
+    } else {
+        if (__builtin_expect(det > PTK_RCP_FAST_MAX, 0)) inv_det = 1.0f / det;
+        else inv_det = pt_rcp_fast(det);
+    }
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+    if (u < 0.0f || u > 1.0f) return;  // :109
+    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return;  // :117
+    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
+    if (tt > 0.0f && tt < tmax) {  // :125
+        tmax = tt; hu = u; hv = v; hidx = i;
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
 // trace kernel
 // ------------------------------------------------------------------------------------------
+template <bool DET_BOUNDED>
 __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTraceParams P)
 {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -141,32 +234,20 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
         if (__ballot(alive) == 0ull) break;
 
         // ---- intersectWorld (:137-154): every lane, wave-uniform triangle index -------------
+        // Two triangle records in flight: the scalar load of triangle i+1 is issued before the
+        // ~46 VALU ops of triangle i, so its latency is covered by this wave's own work.
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
-        for (int i = 0; i < ntri; ++i) {
-            pt_const_f32p t = T + 16 * i;
-            const float p1x = t[0], p1y = t[1], p1z = t[2];
-            const float e1x = t[3], e1y = t[4], e1z = t[5];
-            const float e2x = t[6], e2y = t[7], e2z = t[8];
-            // pvec = cross(dir, e2); det = dot(e1, pvec)   (:96-97)
-            float pvx = pt_fma(d.y, e2z, -(d.z * e2y));
-            float pvy = pt_fma(d.z, e2x, -(d.x * e2z));
-            float pvz = pt_fma(d.x, e2y, -(d.y * e2x));
-            float det = pt_fma(e1z, pvz, pt_fma(e1y, pvy, e1x * pvx));
-            if (det < 1e-8f || -det > 1e-8f) continue;  // :100
-            float inv_det = 1.0f / det;
-            float tvx = o.x - p1x, tvy = o.y - p1y, tvz = o.z - p1z;
-            float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-            if (u < 0.0f || u > 1.0f) continue;  // :109
-            float qvx = pt_fma(tvy, e1z, -(tvz * e1y));
-            float qvy = pt_fma(tvz, e1x, -(tvx * e1z));
-            float qvz = pt_fma(tvx, e1y, -(tvy * e1x));
-            float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-            if (v < 0.0f || u + v > 1.0f) continue;  // :117
-            float tt = pt_fma(e2z, qvz, pt_fma(e2y, qvy, e2x * qvx)) * inv_det;
-            if (tt > 0.0f && tt < tmax) {  // :125
-                tmax = tt; hu = u; hv = v; hidx = i;
+        if (ntri > 0) {
+            PtTriRec a = pt_load_tri(T, 0);
+            int i = 0;
+            for (; i + 1 < ntri; i += 2) {
+                PtTriRec b = pt_load_tri(T, i + 1);
+                pt_tri_test<DET_BOUNDED>(a, i, o, d, tmax, hu, hv, hidx);
+                a = pt_load_tri(T, i + 2 < ntri ? i + 2 : i + 1);
+                pt_tri_test<DET_BOUNDED>(b, i + 1, o, d, tmax, hu, hv, hidx);
             }
+            if (i < ntri) pt_tri_test<DET_BOUNDED>(a, i, o, d, tmax, hu, hv, hidx);
         }
 
         // ---- shade (:229-258) --------------------------------------------------------------
@@ -212,11 +293,11 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
                 pt_sincos(phi, sp, cp);
                 float sinTheta, cosTheta;
                 if (type == 2) {
-                    cosTheta = __builtin_sqrtf((1.0f - xi) / (xi * (rough * rough - 1.0f) + 1.0f));
-                    sinTheta = __builtin_sqrtf(pt_max(0.0f, 1.0f - cosTheta * cosTheta));
+                    cosTheta = pt_sqrt((1.0f - xi) / (xi * (rough * rough - 1.0f) + 1.0f));
+                    sinTheta = pt_sqrt(pt_max(0.0f, 1.0f - cosTheta * cosTheta));
                 } else {
-                    sinTheta = __builtin_sqrtf(xi);
-                    cosTheta = __builtin_sqrtf(1.0f - xi);
+                    sinTheta = pt_sqrt(xi);
+                    cosTheta = pt_sqrt(1.0f - xi);
                 }
                 f3 a = scale3(scale3(sv, cp), sinTheta);
                 f3 b = scale3(scale3(tv, sp), sinTheta);
@@ -367,16 +448,19 @@ __global__ void pt_fill_i32_kernel(int32_t* dst, int32_t value, int n)
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, hipStream_t s)
+hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
+                              hipStream_t s)
 {
-    if (ntri <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pt_prep_kernel, dim3((ntri + 255) / 256), dim3(256), 0, s, raw, out, ntri);
+    hipError_t e = hipMemsetAsync(det_bound_bits, 0, sizeof(unsigned int), s);
+    if (e != hipSuccess || ntri <= 0) return e;
+    hipLaunchKernelGGL(pt_prep_kernel, dim3((ntri + 255) / 256), dim3(256), 0, s, raw, out, ntri, det_bound_bits);
     return hipGetLastError();
 }
 
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, hipStream_t s)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, hipStream_t s)
 {
-    hipLaunchKernelGGL(pt_trace_kernel, dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+    if (det_bounded) hipLaunchKernelGGL(pt_trace_kernel<true>, dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(pt_trace_kernel<false>, dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
     return hipGetLastError();
 }
 
@@ -414,7 +498,7 @@ hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s)
 int ptk_trace_blocks_per_cu(void)
 {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel, PT_TRACE_THREADS, 0) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true>, PT_TRACE_THREADS, 0) != hipSuccess || nb < 1)
         nb = 2;
     return nb;
 }

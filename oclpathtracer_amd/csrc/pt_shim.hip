@@ -91,6 +91,8 @@ struct pt_device_s {
     const pt_buffer_s* prep_src;
     uint64_t prep_version;
     int prep_ntri;
+    bool prep_det_bounded;      // scene extent allows the short exact reciprocal
+    unsigned int* det_bound_dev;  // device word written by the prep kernel
     // fused-render workspace
     float4* rad;
     size_t rad_bytes;
@@ -194,7 +196,8 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_profile = 0;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
-    if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc(&d->det_bound_dev, sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
@@ -218,6 +221,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->prep) hipFree(d->prep);
     if (d->rad) hipFree(d->rad);
     if (d->counters) hipFree(d->counters);
+    if (d->det_bound_dev) hipFree(d->det_bound_dev);
     for (int k = 0; k < PT_PROF_KINDS; ++k)
         for (auto& pr : d->prof_pairs[k]) {
             hipEventDestroy(pr.first);
@@ -592,7 +596,13 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     }
     // wrapped (caller-owned) memory can change behind our back: always re-prepare it
     if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned) return PT_OK;
-    HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->stream));
+    HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->det_bound_dev, d->stream));
+    unsigned int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, d->det_bound_dev, sizeof bits, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));  // once per scene upload
+    float bound;
+    memcpy(&bound, &bits, sizeof bound);
+    d->prep_det_bounded = bound <= PT_DET_BOUND_MAX;  // false for NaN / Inf too
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
@@ -694,7 +704,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;

@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptshim.so")
+# PT_SHIM_LIB lets an experiment point at an alternative build of the same ABI (A/B kernel variants)
+LIB_PATH = os.environ.get("PT_SHIM_LIB") or os.path.join(_HERE, "libptshim.so")
 
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE = range(1, 8)
