@@ -106,31 +106,42 @@ PTK_DEV float pt_random_float(uint32_t& seed)
     return (float)s * 2.3283064365386963e-10f;
 }
 
+// A binary64 literal pinned to an SGPR pair at its point of use.  Left alone, hipcc hoists the
+// polynomial coefficients out of the bounce loop into VGPR pairs that stay live through the whole
+// kernel (27 VGPRs for sin/cos: 91 -> 64 registers, 5 -> 8 waves per SIMD without them); v_fma_f64
+// takes one SGPR-pair operand for free, and two s_mov per coefficient per bounce cost nothing.
+PTK_DEV double pt_k64(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
 // ---- sin/cos of phi >= 0: Cody-Waite by pi/2 in binary64, Taylor to r^15 / r^16, one rounding ----
 PTK_DEV void pt_sincos(float phi, float& s_out, float& c_out)
 {
     double x = (double)phi;
-    int k = (int)(x * PTK_TWO_OVER_PI + 0.5);
+    int k = (int)(x * pt_k64(PTK_TWO_OVER_PI) + 0.5);
     double kd = (double)k;
-    double r = pt_fmad(-kd, PTK_PIO2_HI, x);
-    r = pt_fmad(-kd, PTK_PIO2_LO, r);
+    double r = pt_fmad(-kd, pt_k64(PTK_PIO2_HI), x);
+    r = pt_fmad(-kd, pt_k64(PTK_PIO2_LO), r);
     double r2 = r * r;
-    double ps = PTK_SIN_S6;
-    ps = pt_fmad(ps, r2, PTK_SIN_S5);
-    ps = pt_fmad(ps, r2, PTK_SIN_S4);
-    ps = pt_fmad(ps, r2, PTK_SIN_S3);
-    ps = pt_fmad(ps, r2, PTK_SIN_S2);
-    ps = pt_fmad(ps, r2, PTK_SIN_S1);
-    ps = pt_fmad(ps, r2, PTK_SIN_S0);
+    double ps = pt_k64(PTK_SIN_S6);
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S5));
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S4));
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S3));
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S2));
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S1));
+    ps = pt_fmad(ps, r2, pt_k64(PTK_SIN_S0));
     double sn = pt_fmad(r * r2, ps, r);
-    double pc = PTK_COS_C7;
-    pc = pt_fmad(pc, r2, PTK_COS_C6);
-    pc = pt_fmad(pc, r2, PTK_COS_C5);
-    pc = pt_fmad(pc, r2, PTK_COS_C4);
-    pc = pt_fmad(pc, r2, PTK_COS_C3);
-    pc = pt_fmad(pc, r2, PTK_COS_C2);
-    pc = pt_fmad(pc, r2, PTK_COS_C1);
-    pc = pt_fmad(pc, r2, PTK_COS_C0);
+    __builtin_amdgcn_sched_barrier(0);  // one Horner chain at a time: halves the live f64 registers
+    double pc = pt_k64(PTK_COS_C7);
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C6));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C5));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C4));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C3));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C2));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C1));
+    pc = pt_fmad(pc, r2, pt_k64(PTK_COS_C0));
     double cs = pt_fmad(r2, pc, 1.0);
     int q = k & 3;
     double so = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;

@@ -170,6 +170,17 @@ PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, flo
 // ------------------------------------------------------------------------------------------
 // trace kernel
 // ------------------------------------------------------------------------------------------
+// PT_STAMPS=1 is a DIAGNOSTIC build (tools/gpu_stamps.sh): per-phase s_memtime shares of a
+// wave-bounce go to stats[2..5]; never shipped, never timed for the bench.
+#ifndef PT_STAMPS
+#define PT_STAMPS 0
+#endif
+#if PT_STAMPS
+#define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_STAMP(var) do { } while (0)
+#endif
+
 template <bool DET_BOUNDED>
 __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTraceParams P)
 {
@@ -189,8 +200,12 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
     int bounce = 0;
     unsigned lp = 0, fl = 0;
     unsigned n_rays = 0, n_samples = 0;
+#if PT_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0;
+#endif
 
     for (;;) {
+        PT_STAMP(t0);
         // ---- regeneration: dead lanes take the next samples of the wave's range ----------
         unsigned long long need = __ballot(!alive);
         while (need != 0ull && !exhausted) {
@@ -232,6 +247,7 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
             need = __ballot(!alive);
         }
         if (__ballot(alive) == 0ull) break;
+        PT_STAMP(t1);
 
         // ---- intersectWorld (:137-154): every lane, wave-uniform triangle index -------------
         // Two triangle records in flight: the scalar load of triangle i+1 is issued before the
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
             if (i < ntri) pt_tri_test<DET_BOUNDED>(a, i, o, d, tmax, hu, hv, hidx);
         }
 
+        PT_STAMP(t2);
         // ---- shade (:229-258) --------------------------------------------------------------
         if (alive) {
             bool finished = false;
@@ -259,6 +276,16 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
                 L = add3(L, scale3(mask, bg));  // :235
                 finished = true;
             } else {
+                // The direction sample's angle first: sin/cos run in binary64 and are the register
+                // peak of the kernel; here only the path state is live.  Both BRDFs draw phi first,
+                // then the second uniform (:163-164, :182-183).
+                float phi = PTK_TWO_PI * pt_random_float(seed);
+                float xi = pt_random_float(seed);
+                float sp, cp;
+                __builtin_amdgcn_sched_barrier(0);
+                pt_sincos(phi, sp, cp);
+                __builtin_amdgcn_sched_barrier(0);
+
                 // deferred HitRecord of the closest hit (:127-130): same values as writing it
                 // at every acceptance, only the last one is read.
                 const float4 nid = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(P.tris + hidx) + 12);
@@ -283,14 +310,10 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
                 f3 wo = neg3(d);
 
                 // sampleHemisphereCosine (:161-172) and sampleGGX (:180-192) share everything
-                // except (sinTheta, cosTheta); both draw phi first, then the second uniform.
-                float phi = PTK_TWO_PI * pt_random_float(seed);
-                float xi = pt_random_float(seed);
+                // except (sinTheta, cosTheta)
                 f3 axis = __builtin_fabsf(n.x) > 0.001f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
                 f3 tv = normalize3(cross3(axis, n));
                 f3 sv = cross3(n, tv);
-                float sp, cp;
-                pt_sincos(phi, sp, cp);
                 float sinTheta, cosTheta;
                 if (type == 2) {
                     cosTheta = pt_sqrt((1.0f - xi) / (xi * (rough * rough - 1.0f) + 1.0f));
@@ -351,8 +374,20 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
                 alive = false;
             }
         }
+#if PT_STAMPS
+        PT_STAMP(t3);
+        c_regen += t1 - t0; c_loop += t2 - t1; c_shade += t3 - t2; c_iters++;
+#endif
     }
 
+#if PT_STAMPS
+    if (P.stats && lane == 0) {
+        atomicAdd(&P.stats[2], c_regen);
+        atomicAdd(&P.stats[3], c_loop);
+        atomicAdd(&P.stats[4], c_shade);
+        atomicAdd(&P.stats[5], c_iters);
+    }
+#endif
     if (P.stats) {
         // wave reduction of the work counters, one atomic pair per wave
         unsigned long long r = n_rays, s = n_samples;
