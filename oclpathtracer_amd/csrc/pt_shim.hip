@@ -239,7 +239,11 @@ extern "C" int pt_device_info(pt_device_t d, int kind, char out[128])
     out[0] = 0;
     switch (kind) {
     case PT_INFO_NAME:
-    case PT_INFO_BOARD: snprintf(out, 128, "%s", d->prop.name); break;
+    case PT_INFO_BOARD:
+        // some driver stacks report an empty marketing name; fall back to the ISA name
+        if (d->prop.name[0]) snprintf(out, 128, "%s", d->prop.name);
+        else snprintf(out, 128, "AMD Instinct (%.*s)", 96, d->prop.gcnArchName);
+        break;
     case PT_INFO_VENDOR: snprintf(out, 128, "Advanced Micro Devices, Inc."); break;
     case PT_INFO_VERSION: {
         int rt = 0;
@@ -336,6 +340,7 @@ extern "C" int pt_buffer_alloc(pt_device_t d, size_t bytes, pt_buffer_t* out)
         hipError_t e = hipMalloc(&b->dptr, bytes);
         if (e != hipSuccess) {
             delete b;
+            (void)hipGetLastError();  // clear the sticky error: later launches check hipGetLastError()
             return fail(PT_ERR_OOM, "hipMalloc(%zu) failed: %s (used %llu bytes)", bytes, hipGetErrorString(e),
                         (unsigned long long)d->used);
         }
