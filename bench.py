@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="trace kernel: 0 library default, 1 lane-regenerating, 2 octant-sorted")
     args = ap.parse_args()
 
     import torch  # first: the shim must bind to the HIP runtime torch already loaded
@@ -124,6 +125,7 @@ def main():
     assert adl.init(adl.TYPE_HIP), "adl.init failed"
     dev = adl.DeviceUtils.allocate(adl.TYPE_HIP, adl.Config(local_rank))
     lib = shim.load()
+    dev.setOption(shim.PT_OPT_TRACE_VARIANT, args.variant)
     img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True)
 
     def step():

@@ -100,7 +100,11 @@ enum pt_option {
     PT_OPT_CHUNK_FRAMES = 1,
     /* Device::toggleProfiling(PROFILE_RETURN_TIME) (Adl.h:171): launches synchronise and
      * return their duration in ms (AdlKernelUtilsCL.cpp:470-487). */
-    PT_OPT_PROFILE_RETURN_TIME = 2
+    PT_OPT_PROFILE_RETURN_TIME = 2,
+    /* which trace kernel renders: 0 = library default, 1 = lane-regenerating waves,
+     * 2 = octant-sorted workgroups (rays regrouped by direction octant through LDS every bounce).
+     * All variants produce identical pixels. */
+    PT_OPT_TRACE_VARIANT = 3
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

@@ -25,7 +25,10 @@ struct PtPrepTriangle {
 static_assert(sizeof(PtPrepTriangle) == 64, "prep layout");
 
 #define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
-#define PT_TRACE_THREADS 256   // 4 waves per workgroup
+#define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
+#ifndef PT_SORT_THREADS
+#define PT_SORT_THREADS 512    // 8 waves per workgroup (variant 2: octant-sorted)
+#endif
 
 struct PtTraceParams {
     const PtPrepTriangle* tris;
@@ -53,11 +56,14 @@ struct PtFoldParams {
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s);
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, hipStream_t s);
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool sorted, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
+#ifndef PT_DEFAULT_SORTED
+#define PT_DEFAULT_SORTED 0  // which variant PT_OPT_TRACE_VARIANT = 0 (auto) picks
+#endif
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);
 hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width, int height, int stripe_rows,
                                 int n_ranks, int slab_rows, hipStream_t s);
 hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStream_t s);
 hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s);
-int ptk_trace_blocks_per_cu(void);
+int ptk_trace_blocks_per_cu(bool sorted);

@@ -83,7 +83,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -97,7 +97,7 @@ struct pt_device_s {
     float4* rad;
     size_t rad_bytes;
     unsigned int* counters;  // PT_MAX_CHUNKS batch counters
-    int blocks_per_cu;
+    int blocks_per_cu, blocks_per_cu_sorted;
     PendingFrames pending;
     // per-kernel timing (pt_profile_*)
     bool prof_on;
@@ -194,6 +194,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_batch = 1;
     d->opt_chunk = 0;
     d->opt_profile = 0;
+    d->opt_variant = 0;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
@@ -202,7 +203,8 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
     }
-    d->blocks_per_cu = ptk_trace_blocks_per_cu();
+    d->blocks_per_cu = ptk_trace_blocks_per_cu(false);
+    d->blocks_per_cu_sorted = ptk_trace_blocks_per_cu(true);
     d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
     *out = d;
     return PT_OK;
@@ -306,6 +308,10 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
     case PT_OPT_PROFILE_RETURN_TIME:
         d->opt_profile = value ? 1 : 0;
         return PT_OK;
+    case PT_OPT_TRACE_VARIANT:
+        if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "trace variant must be 0 (auto), 1 or 2");
+        d->opt_variant = value;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -317,6 +323,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_BATCH_FRAMES: return d->opt_batch;
     case PT_OPT_CHUNK_FRAMES: return d->opt_chunk;
     case PT_OPT_PROFILE_RETURN_TIME: return d->opt_profile;
+    case PT_OPT_TRACE_VARIANT: return d->opt_variant;
     default: return -1;
     }
 }
@@ -703,13 +710,15 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.batches_per_frame = bpf;
         tp.total_batches = (uint32_t)total_batches;
         // persistent grid: fill the chip, but never more waves than batches
+        const bool sorted = d->opt_variant == 2 || (d->opt_variant == 0 && PT_DEFAULT_SORTED);
+        const int wg_waves = (sorted ? PT_SORT_THREADS : PT_TRACE_THREADS) / 64;
         uint64_t waves_needed = total_batches;
-        int blocks = d->prop.multiProcessorCount * d->blocks_per_cu;
-        uint64_t blocks_needed = (waves_needed + (PT_TRACE_THREADS / 64) - 1) / (PT_TRACE_THREADS / 64);
+        int blocks = d->prop.multiProcessorCount * (sorted ? d->blocks_per_cu_sorted : d->blocks_per_cu);
+        uint64_t blocks_needed = (waves_needed + wg_waves - 1) / wg_waves;
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, sorted, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;

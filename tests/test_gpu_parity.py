@@ -19,16 +19,22 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4  # BASELINE.json north_star: "pixels within 1e-4 RMS of the OpenCL reference"
 
 
-def _render_gpu(device, tris, mats, W, H, frames, *, depth=16, frame_begin=0, fb_init=None, **kw):
+VARIANTS = [1, 2]  # PT_OPT_TRACE_VARIANT: lane-regenerating waves / octant-sorted workgroups
+
+
+def _render_gpu(device, tris, mats, W, H, frames, *, depth=16, frame_begin=0, fb_init=None, variant=0, **kw):
+    from oclpathtracer_amd import shim
     from oclpathtracer_amd.render import Renderer
 
     r = Renderer(device, tris, mats, W, H, **kw)
+    device.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
     try:
         if fb_init is not None:
             r.fb.write(np.ascontiguousarray(fb_init, np.float32), r.local_pixels)
         r.render(frames, frame_begin=frame_begin, max_bounces=depth)
         return r.read()
     finally:
+        device.setOption(shim.PT_OPT_TRACE_VARIANT, 0)
         r.release()
 
 
@@ -36,13 +42,14 @@ GOLDEN_CASES = ["cornell_64x64_f1_d16", "cornell_64x64_f2_d16", "cornell_64x64_f
                 "cornell_40x24_f5_d16"]
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_fused_render_matches_golden(device, cornell, name):
+def test_fused_render_matches_golden(device, cornell, name, variant):
     with open(os.path.join(GOLDEN, "work_counters.json")) as f:
         meta = json.load(f)[name]
     want = np.load(os.path.join(GOLDEN, name + ".npy"))
     tris, mats = cornell
-    got = _render_gpu(device, tris, mats, meta["W"], meta["H"], meta["frames"], depth=meta["max_bounces"])
+    got = _render_gpu(device, tris, mats, meta["W"], meta["H"], meta["frames"], depth=meta["max_bounces"], variant=variant)
     assert_fb_equal(got, want, name)
     assert rms_diff(got, want) <= RMS_TOL
 
@@ -52,17 +59,21 @@ def test_fused_render_matches_golden(device, cornell, name):
                                               (512, 512, 4, 2),        # configs[1] shape, fewer frames
                                               (96, 33, 7, 16),         # ragged
                                               (1, 1, 3, 16), (64, 1, 2, 16), (1, 70, 2, 5)])
-def test_fused_render_matches_oracle(device, cornell, oracle, W, H, frames, depth):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_fused_render_matches_oracle(device, cornell, oracle, W, H, frames, depth, variant):
     tris, mats = cornell
     want, st = oracle.render(tris, mats, W, H, frames, max_bounces=depth, want_stats=True)
+    from oclpathtracer_amd import shim
     from oclpathtracer_amd.render import Renderer
 
     r = Renderer(device, tris, mats, W, H, want_stats=True)
+    device.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
     try:
         r.render(frames, max_bounces=depth)
         got = r.read()
         gst = r.read_stats()
     finally:
+        device.setOption(shim.PT_OPT_TRACE_VARIANT, 0)
         r.release()
     assert_fb_equal(got, want, "%dx%d f%d d%d" % (W, H, frames, depth))
     assert rms_diff(got, want) <= RMS_TOL
@@ -79,7 +90,8 @@ def test_configs1_direct_full_size(device, cornell, oracle):
     assert_fb_equal(got, want, "C2")
 
 
-def test_configs2_full_size_sampled_pixels(device, cornell, oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_configs2_full_size_sampled_pixels(device, cornell, oracle, variant):
     """BASELINE configs[2]: 1024x1024, 256 spp, depth 16 rendered in full on the GPU; the oracle
     recomputes 2048 seeded pixel positions through all 256 frames (pixels are independent,
     GenerateColors.cl:305-321) and those must match bit for bit.  Whole-image properties: w == 1
@@ -87,7 +99,7 @@ def test_configs2_full_size_sampled_pixels(device, cornell, oracle):
     tris, mats = cornell
     W = H = 1024
     frames = 256
-    got = _render_gpu(device, tris, mats, W, H, frames).reshape(H * W, 4)
+    got = _render_gpu(device, tris, mats, W, H, frames, variant=variant).reshape(H * W, 4)
     assert np.all(got[:, 3] == 1.0)
     assert not np.any(got[:, :3] < 0)
     rng = np.random.default_rng(20261004)
@@ -201,14 +213,15 @@ def test_stripe_sharding_reassembles_bit_exact(device, cornell, n_ranks, stripe_
     assert_fb_equal(out, full, "assembled image")
 
 
-def test_soup_scene_runtime_triangle_count(device, oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_soup_scene_runtime_triangle_count(device, oracle, variant):
     """Runtime N_tri / N_mat (BASELINE configs[4] shape at a size the oracle finishes quickly)."""
     from oclpathtracer_amd import scene
 
     tris, mats = scene.make_soup(2000)
     W, H, frames = 48, 32, 2
     want = oracle.render(tris, mats, W, H, frames)
-    got = _render_gpu(device, tris, mats, W, H, frames)
+    got = _render_gpu(device, tris, mats, W, H, frames, variant=variant)
     assert_fb_equal(got, want, "soup 2000")
 
 

@@ -6,17 +6,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oclpathtracer_amd import adl, scene, shim
 from oclpathtracer_amd.render import Renderer
-W, H, spp, depth = (int(x) for x in (sys.argv[1:5] + ["1024", "1024", "64", "16"][len(sys.argv) - 1:]))
+args = sys.argv[1:]
+variant = int(args.pop(0)) if args else 1
+W, H, spp, depth = (int(x) for x in (args[:4] + ["1024", "1024", "64", "16"][len(args):]))
 assert adl.init()
 dev = adl.DeviceUtils.allocate()
 t, m = scene.load_model()
+dev.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
 r = Renderer(dev, t, m, W, H, want_stats=True)
 r.render(spp, max_bounces=depth)
 out = np.zeros(shim.PT_STAT_WORDS, np.uint64)
 r.stats.read(out, shim.PT_STAT_WORDS); dev.waitForCompletion()
-samples, rays, c_regen, c_loop, c_shade, iters = (int(x) for x in out[:6])
-tot = c_regen + c_loop + c_shade
+samples, rays, c_regen, c_loop, c_shade, iters, c_sort, c_full = (int(x) for x in out[:8])
+tot = c_regen + c_loop + c_shade + c_sort
+print("variant", variant, " triangles fully tested per wave-iteration: %.1f" % (c_full / max(iters, 1)))
 print("samples %d rays %d wave-iterations %d  lanes busy per iteration %.1f/64" % (samples, rays, iters, rays / max(iters, 1)))
-for n, c in (("regen", c_regen), ("loop", c_loop), ("shade", c_shade)):
+for n, c in (("regen", c_regen), ("sort", c_sort), ("loop", c_loop), ("shade", c_shade)):
     print("%-6s %5.1f%%   %.0f ticks per wave-iteration" % (n, 100.0 * c / max(tot, 1), c / max(iters, 1)))
 r.release(); adl.DeviceUtils.deallocate(dev)
