@@ -26,6 +26,8 @@ static_assert(sizeof(PtPrepTriangle) == 64, "prep layout");
 
 #define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
+#define PT_LDS_TRI_STRIDE 12    // dwords per triangle record in the LDS copy (p1, e1, e2, 3 pad)
+#define PT_LDS_TRI_MAX 256      // scenes up to this many triangles keep the copy (12 KiB per workgroup)
 #ifndef PT_SORT_THREADS
 #define PT_SORT_THREADS 512    // 8 waves per workgroup (variant 2: octant-sorted)
 #endif

@@ -98,11 +98,13 @@ PTK_DEV PtTriRec pt_load_tri(pt_const_f32p T, int i)
 
 // DET_BOUNDED: the host has verified |e1|*|e2| <= 2e19 for every triangle, so det <= 1e20 and
 // the short exact reciprocal applies to every front-facing triangle.
-#ifndef PT_FLAT_TRI
-#define PT_FLAT_TRI 1
+#ifndef PT_TWO_PASS
+#define PT_TWO_PASS 1  // 1: two-pass closest hit (uniform det+u pass, per-lane survivor pass); 0: one flat pass
+#endif
+#ifndef PT_TRACK_UV
+#define PT_TRACK_UV 0  // 1: carry (u,v) of the closest hit through the loop; 0: recompute them for the winner
 #endif
 
-#if PT_FLAT_TRI
 // Straight-line form: every lane evaluates the whole test and the five early returns of the
 // reference (:100,:109,:117,:125) become one predicate.  Values computed past a failed test are
 // never observed, so the accepted (t,u,v,index) are those of the branchy form bit for bit.  With
@@ -130,42 +132,163 @@ PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, flo
     float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
     ok &= (tt > 0.0f) & (tt < tmax);  // :125
     tmax = ok ? tt : tmax;
+    hidx = ok ? i : hidx;
+#if PT_TRACK_UV
     hu = ok ? u : hu;
     hv = ok ? v : hv;
-    hidx = ok ? i : hidx;
-}
 #else
+    (void)hu; (void)hv;  // recomputed once for the winner: pt_hit_uv
+#endif
+}
+
+// (u, v) of the winning triangle, recomputed with the arithmetic of the test above from the
+// triangle's record (per-lane vector loads): the same operations on the same operands give the
+// same bits as carrying (u, v) through the 36-triangle loop, for 2 fewer v_cndmask per triangle.
 template <bool DET_BOUNDED>
-PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
+PTK_DEV void pt_hit_uv(const PtPrepTriangle* tris, int hidx, const f3& o, const f3& d, float& hu, float& hv)
 {
-    // pvec = cross(dir, e2); det = dot(e1, pvec)   (:96-97)
+    const float* t = reinterpret_cast<const float*>(tris + hidx);
+    const float4 q0 = *reinterpret_cast<const float4*>(t);      // p1.xyz e1.x
+    const float4 q1 = *reinterpret_cast<const float4*>(t + 4);  // e1.yz e2.xy
+    const float e2z = t[8];
+    PtTriRec r;
+    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+    r.e2x = q1.z; r.e2y = q1.w; r.e2z = e2z;
     float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
     float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
     float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
     float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    if (det < 1e-8f || -det > 1e-8f) return;  // :100
-    // 1.0f / det (:105), correctly rounded; det >= 1e-8 here (or NaN)
-    float inv_det;
+    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    hu = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+    hv = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
+}
+
+// ---- two-pass closest hit -------------------------------------------------------------------------
+// SIMT executes all 44 instructions of the flat test for every lane, but only 9 % of the
+// (ray, triangle) pairs get past the u test (:109) -- 50 % are culled at :100, 41 % fail :109.
+// Pass 1 (wave-uniform triangle, SGPR operands, 24 VALU): det, 1/det, u and the predicate
+// "passes :100 and :109", recorded as one bit per triangle in a per-lane mask.
+// Pass 2 (per lane): each lane walks ITS surviving triangles in ascending index and runs the rest
+// of the test on them (record fetched with per-lane vector loads, L1-resident); the wave iterates
+// max-over-lanes(#survivors) times, ~8 for the Cornell box instead of 36.
+// Exactness: a pair that fails :100 or :109 can never be accepted, the survivors are tested with
+// the same operations on the same operands, in the same (ascending) order, against the same
+// running tmax -- the accepted (t, index) are those of the one-pass loop bit for bit.
+template <bool DET_BOUNDED>
+PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
+{
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    bool ok = !(det < 1e-8f);  // :100
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    float un = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx));  // u = un * RN(1/det)
     if (DET_BOUNDED) {
-        inv_det = pt_rcp_fast(det);
+        // Pass 2 re-applies :100 and :109 exactly, so pass 1 only has to keep a SUPERSET of the
+        // pairs that pass them -- without the reciprocal (a quarter-rate instruction + 2 fma).
+        // With det in [1e-8, 1e20] (DET_BOUNDED) and inv = RN(1/det) in [1e-20, 1e8]:
+        //   un < -1e-24        =>  un*inv <= -1e-44, rounds to a negative non-zero  =>  u < 0
+        //   un > det*1.000001f =>  un*inv >= 1.000001*(1-2^-24)^2 > 1 + 8e-7        =>  u > 1
+        // A NaN in det or un fails every "<"/">" here and stays in the mask, as it passes
+        // :100/:109 in the reference.
+        ok &= !(un < -1e-24f) & !(un > det * 1.000001f);
     } else {
-        if (__builtin_expect(det > PTK_RCP_FAST_MAX, 0)) inv_det = 1.0f / det;
-        else inv_det = pt_rcp_fast(det);
+        float u = un * (1.0f / det);
+        ok &= !(u < 0.0f) & !(u > 1.0f);  // :109
     }
+    return ok ? 1u : 0u;
+}
+
+// dynamic LDS of the trace kernels: the workgroup's copy of the hot triangle records
+extern __shared__ __attribute__((aligned(16))) float pt_lds_tab[];
+
+// record i for pass 2: from the LDS copy (stride PT_LDS_TRI_STRIDE dwords, 32-bit LDS addressing)
+// or, for scenes too large for it, from the prepared table in global memory (stride 16)
+template <bool LDS_TABLE>
+PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
+{
+    float4 q0, q1;
+    float e2z;
+    if (LDS_TABLE) {
+        const int w = i * PT_LDS_TRI_STRIDE;
+        q0 = *reinterpret_cast<const float4*>(&pt_lds_tab[w]);
+        q1 = *reinterpret_cast<const float4*>(&pt_lds_tab[w + 4]);
+        e2z = pt_lds_tab[w + 8];
+    } else {
+        const float* t = reinterpret_cast<const float*>(tris + i);
+        q0 = *reinterpret_cast<const float4*>(t);
+        q1 = *reinterpret_cast<const float4*>(t + 4);
+        e2z = t[8];
+    }
+    PtTriRec r;
+    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;  // p1.xyz e1.x | e1.yz e2.xy | e2.z
+    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+    r.e2x = q1.z; r.e2y = q1.w; r.e2z = e2z;
+    return r;
+}
+
+template <bool DET_BOUNDED>
+PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, const f3& d, float& tmax, int& hidx)
+{
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
     float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
     float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    if (u < 0.0f || u > 1.0f) return;  // :109
+    bool ok = valid & !(det < 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109 (pass 1 kept a superset)
     float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
     float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
     float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
     float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return;  // :117
+    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
     float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
-    if (tt > 0.0f && tt < tmax) {  // :125
-        tmax = tt; hu = u; hv = v; hidx = i;
-    }
+    ok &= (tt > 0.0f) & (tt < tmax);  // :125
+    tmax = ok ? tt : tmax;
+    hidx = ok ? i : hidx;
 }
-#endif
+
+// closest hit over triangles [0, ntri): chunks of 32 triangles, pass 1 then pass 2 per chunk.
+// (Software-pipelining pass 2 -- fetching the next survivor's record during the current test --
+// was measured slower: 64.8 ms against 61.1 ms; the register copies cost more than the LDS latency
+// that 7 waves per SIMD already hide.)
+template <bool DET_BOUNDED, bool LDS_TABLE>
+PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
+                                       bool alive, float& tmax, int& hidx)
+{
+    unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
+    for (int base = 0; base < ntri; base += 32) {
+        const int n = ntri - base < 32 ? ntri - base : 32;
+        unsigned m = 0u;  // bit j <-> triangle base + j
+        PtTriRec a = pt_load_tri(T, base);
+        int j = 0;
+        for (; j + 1 < n; j += 2) {
+            PtTriRec b = pt_load_tri(T, base + j + 1);
+            m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
+            a = pt_load_tri(T, base + (j + 2 < n ? j + 2 : j + 1));
+            m |= pt_tri_pass1<DET_BOUNDED>(b, o, d) << (j + 1);
+        }
+        if (j < n) m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
+        if (!alive) m = 0u;  // a dead lane's stale ray must not cost pass-2 iterations
+        // every lane tests its next survivor (index 0 and ok = false once it has none left)
+        while (__ballot(m != 0u) != 0ull) {
+            ++steps;
+            const bool valid = m != 0u;
+            const int i = base + (valid ? __builtin_ctz(m) : 0);
+            m &= m - 1u;
+            const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+            pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hidx);
+        }
+    }
+    return steps;
+}
 
 // ------------------------------------------------------------------------------------------
 // trace kernels
@@ -245,6 +368,7 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
 }
 
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
+template <bool DET_BOUNDED>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
                       unsigned& n_rays, unsigned& n_samples)
 {
@@ -272,6 +396,9 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         int mid = __float_as_int(nid.w);
         mid = mid < 0 ? 0 : (mid >= P.nmat ? P.nmat - 1 : mid);  // never fault on a corrupt id
         f3 p = add3(s.o, scale3(s.d, tmax));
+#if !PT_TRACK_UV
+        pt_hit_uv<DET_BOUNDED>(P.tris, hidx, s.o, s.d, hu, hv);
+#endif
         float w = 1.0f - hu - hv;
         f3 n = normalize3(add3(add3(scale3(N, hu), scale3(N, hv)), scale3(N, w)));
 
@@ -372,12 +499,23 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 // ---- variant 1: lane-regenerating waves, no exchange between lanes -------------------------------
 // (A fully unrolled 36-triangle specialisation was tried and dropped: LLVM hoists the unrolled
 // triangles' temporaries, 127 VGPRs / 4 waves per SIMD, 76.0 ms against 70.2 ms for this loop.)
-template <bool DET_BOUNDED>
+// LDS_TABLE: the workgroup keeps a copy of the prepared triangle records (stride 12 dwords:
+// conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
+// 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
+template <bool DET_BOUNDED, bool LDS_TABLE>
 __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTraceParams P)
 {
     const unsigned lane = pt_lane_id();
     pt_const_f32p T = (pt_const_f32p)(const float*)P.tris;
     const int ntri = P.ntri;
+    if (LDS_TABLE) {
+        const float* g = reinterpret_cast<const float*>(P.tris);
+        for (int k = (int)threadIdx.x; k < ntri * PT_LDS_TRI_STRIDE; k += PT_TRACE_THREADS) {
+            int tri = k / PT_LDS_TRI_STRIDE, w = k - tri * PT_LDS_TRI_STRIDE;
+            pt_lds_tab[k] = g[tri * 16 + w];
+        }
+        __syncthreads();
+    }
 
     PtQueue q = { 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
     bool alive = false;
@@ -387,7 +525,7 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
     s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
     unsigned n_rays = 0, n_samples = 0;
 #if PT_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0;
 #endif
 
     for (;;) {
@@ -401,6 +539,14 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
         // ~46 VALU ops of triangle i, so its latency is covered by this wave's own work.
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
+#if PT_TWO_PASS && !PT_TRACK_UV
+        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hidx);
+#if PT_STAMPS
+        c_steps += p2steps;
+#else
+        (void)p2steps;
+#endif
+#else
         if (ntri > 0) {
             PtTriRec a = pt_load_tri(T, 0);
             int i = 0;
@@ -412,9 +558,10 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
             }
             if (i < ntri) pt_tri_test<DET_BOUNDED>(a, i, s.o, s.d, tmax, hu, hv, hidx);
         }
+#endif
 
         PT_STAMP(t2);
-        if (alive) pt_shade(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #if PT_STAMPS
         PT_STAMP(t3);
         c_regen += t1 - t0; c_loop += t2 - t1; c_shade += t3 - t2; c_iters++;
@@ -427,6 +574,7 @@ __global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTrac
         atomicAdd(&P.stats[3], c_loop);
         atomicAdd(&P.stats[4], c_shade);
         atomicAdd(&P.stats[5], c_iters);
+        atomicAdd(&P.stats[7], c_steps);
     }
 #endif
     pt_flush_counters(P, lane, n_rays, n_samples);
@@ -471,9 +619,8 @@ PTK_DEV bool pt_tri_test_cull(const PtTriRec& r, int i, const f3& o, const f3& d
     float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
     ok &= (tt > 0.0f) & (tt < tmax);  // :125
     tmax = ok ? tt : tmax;
-    hu = ok ? u : hu;
-    hv = ok ? v : hv;
     hidx = ok ? i : hidx;
+    (void)hu; (void)hv;  // recomputed for the winner: pt_hit_uv
     return true;
 }
 
@@ -571,7 +718,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void pt_trace_sorted_kernel(const 
             if (i < ntri) pt_tri_test_cull<DET_BOUNDED>(a, i, s.o, s.d, alive, tmax, hu, hv, hidx);
         }
         PT_STAMP(t3);
-        if (alive) pt_shade(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #if PT_STAMPS
         PT_STAMP(t4);
         c_regen += t1 - t0; c_sort += t2 - t1; c_loop += t3 - t2; c_shade += t4 - t3; c_iters++;
@@ -685,9 +832,13 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, b
     if (sorted) {
         if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
+    } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
+        const size_t lds = (size_t)p.ntri * PT_LDS_TRI_STRIDE * sizeof(float);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
-        if (det_bounded) hipLaunchKernelGGL(pt_trace_kernel<true>, dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
-        else hipLaunchKernelGGL(pt_trace_kernel<false>, dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -727,7 +878,7 @@ int ptk_trace_blocks_per_cu(bool sorted)
 {
     int nb = 0;
     hipError_t e = sorted ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_sorted_kernel<true>, PT_SORT_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true>, PT_TRACE_THREADS, 0);
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true>, PT_TRACE_THREADS, PT_LDS_TRI_MAX * PT_LDS_TRI_STRIDE * sizeof(float));
     if (e != hipSuccess || nb < 1) nb = sorted ? 1 : 2;
     return nb;
 }

@@ -19,7 +19,7 @@ out = np.zeros(shim.PT_STAT_WORDS, np.uint64)
 r.stats.read(out, shim.PT_STAT_WORDS); dev.waitForCompletion()
 samples, rays, c_regen, c_loop, c_shade, iters, c_sort, c_full = (int(x) for x in out[:8])
 tot = c_regen + c_loop + c_shade + c_sort
-print("variant", variant, " triangles fully tested per wave-iteration: %.1f" % (c_full / max(iters, 1)))
+print("variant", variant, " stats[7] per wave-iteration (v1: pass-2 steps, v2: triangles fully tested): %.1f" % (c_full / max(iters, 1)))
 print("samples %d rays %d wave-iterations %d  lanes busy per iteration %.1f/64" % (samples, rays, iters, rays / max(iters, 1)))
 for n, c in (("regen", c_regen), ("sort", c_sort), ("loop", c_loop), ("shade", c_shade)):
     print("%-6s %5.1f%%   %.0f ticks per wave-iteration" % (n, 100.0 * c / max(tot, 1), c / max(iters, 1)))
