@@ -186,9 +186,9 @@ PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
     float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
     float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
     float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    bool ok = !(det < 1e-8f);  // :100
     float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
     float un = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx));  // u = un * RN(1/det)
+    bool ok;
     if (DET_BOUNDED) {
         // Pass 2 re-applies :100 and :109 exactly, so pass 1 only has to keep a SUPERSET of the
         // pairs that pass them -- without the reciprocal (a quarter-rate instruction + 2 fma).
@@ -196,11 +196,12 @@ PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
         //   un < -1e-24        =>  un*inv <= -1e-44, rounds to a negative non-zero  =>  u < 0
         //   un > det*1.000001f =>  un*inv >= 1.000001*(1-2^-24)^2 > 1 + 8e-7        =>  u > 1
         // A NaN in det or un fails every "<"/">" here and stays in the mask, as it passes
-        // :100/:109 in the reference.
-        ok &= !(un < -1e-24f) & !(un > det * 1.000001f);
+        // :100/:109 in the reference.  The cull test (:100) itself is left to pass 2: a pair with
+        // det < 1e-8 survives these two bounds only for det in [-1e-24, 1e-8), which is rare.
+        ok = !(un < -1e-24f) & !(un > det * 1.000001f);
     } else {
         float u = un * (1.0f / det);
-        ok &= !(u < 0.0f) & !(u > 1.0f);  // :109
+        ok = !(det < 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109
     }
     return ok ? 1u : 0u;
 }
@@ -503,7 +504,11 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 // conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
 // 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
 template <bool DET_BOUNDED, bool LDS_TABLE>
-__global__ __launch_bounds__(PT_TRACE_THREADS) void pt_trace_kernel(const PtTraceParams P)
+// 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
+// (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
+// makes hipcc keep 94 SGPRs (2 spilled to VGPR lanes): 60.9 -> 59.8 ms.
+__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
+void pt_trace_kernel(const PtTraceParams P)
 {
     const unsigned lane = pt_lane_id();
     pt_const_f32p T = (pt_const_f32p)(const float*)P.tris;
