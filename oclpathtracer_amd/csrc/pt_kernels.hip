@@ -235,7 +235,8 @@ PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
 }
 
 template <bool DET_BOUNDED>
-PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, const f3& d, float& tmax, int& hidx)
+PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, const f3& d, float& tmax, float& hu,
+                          float& hv, int& hidx)
 {
     float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
     float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
@@ -253,6 +254,8 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
     float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
     ok &= (tt > 0.0f) & (tt < tmax);  // :125
     tmax = ok ? tt : tmax;
+    hu = ok ? u : hu;  // pass 2 runs ~8 times per ray: carrying (u,v) here is cheaper than pt_hit_uv
+    hv = ok ? v : hv;
     hidx = ok ? i : hidx;
 }
 
@@ -262,7 +265,7 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
 // that 7 waves per SIMD already hide.)
 template <bool DET_BOUNDED, bool LDS_TABLE>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
-                                       bool alive, float& tmax, int& hidx)
+                                       bool alive, float& tmax, float& hu, float& hv, int& hidx)
 {
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
     for (int base = 0; base < ntri; base += 32) {
@@ -285,7 +288,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             const int i = base + (valid ? __builtin_ctz(m) : 0);
             m &= m - 1u;
             const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
-            pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hidx);
+            pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
         }
     }
     return steps;
@@ -318,6 +321,7 @@ struct PtPath {
 // wave-uniform slice of the global sample queue
 struct PtQueue {
     unsigned pix, end, frame;
+    unsigned row, col;  // local row / column of `pix` (kept incrementally: no per-lane division)
     bool exhausted;
 };
 
@@ -340,6 +344,8 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
             q.pix = bi * PT_TRACE_BATCH;
             unsigned e = q.pix + PT_TRACE_BATCH;
             q.end = e < P.npix_local ? e : P.npix_local;
+            q.row = q.pix / (unsigned)P.width;  // one wave-uniform division per 256 samples
+            q.col = q.pix - q.row * (unsigned)P.width;
         }
         unsigned n_need = (unsigned)__popcll(need);
         unsigned avail = q.end - q.pix;
@@ -348,12 +354,17 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
         if (!alive && rank < take) {
             s.lp = q.pix + rank;
             s.fl = q.frame;
-            // local pixel -> global pixel id (image rows dealt to ranks in stripes)
-            unsigned lr = s.lp / (unsigned)P.width;
-            unsigned x = s.lp - lr * (unsigned)P.width;
-            unsigned sl = lr / (unsigned)P.stripe_rows;
-            unsigned within = lr - sl * (unsigned)P.stripe_rows;
-            unsigned grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+            // local pixel -> (local row, column): walk from the range's (row, col); a wave takes
+            // at most 64 pixels at a time, so this loops once or twice unless the image is narrow
+            unsigned lr = q.row, x = q.col + rank;
+            while (x >= (unsigned)P.width) { x -= (unsigned)P.width; ++lr; }
+            // local row -> global row (image rows dealt to ranks in stripes)
+            unsigned grow = lr;
+            if (P.n_ranks > 1) {
+                unsigned sl = lr / (unsigned)P.stripe_rows;
+                unsigned within = lr - sl * (unsigned)P.stripe_rows;
+                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+            }
             unsigned gid = grow * (unsigned)P.width + x;
             int frame = P.frame_begin + (int)s.fl;
             s.seed = gid + pt_hash_u32((uint32_t)frame);                           // :308
@@ -364,12 +375,15 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
             alive = true;
         }
         q.pix += take;
+        q.col += take;
+        while (q.col >= (unsigned)P.width) { q.col -= (unsigned)P.width; ++q.row; }
         need = __ballot(!alive);
     }
 }
 
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
-template <bool DET_BOUNDED>
+// HAVE_UV: the caller's closest-hit search carried (u,v); otherwise they are recomputed here
+template <bool DET_BOUNDED, bool HAVE_UV>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
                       unsigned& n_rays, unsigned& n_samples)
 {
@@ -397,9 +411,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         int mid = __float_as_int(nid.w);
         mid = mid < 0 ? 0 : (mid >= P.nmat ? P.nmat - 1 : mid);  // never fault on a corrupt id
         f3 p = add3(s.o, scale3(s.d, tmax));
-#if !PT_TRACK_UV
-        pt_hit_uv<DET_BOUNDED>(P.tris, hidx, s.o, s.d, hu, hv);
-#endif
+        if (!HAVE_UV) pt_hit_uv<DET_BOUNDED>(P.tris, hidx, s.o, s.d, hu, hv);
         float w = 1.0f - hu - hv;
         f3 n = normalize3(add3(add3(scale3(N, hu), scale3(N, hv)), scale3(N, w)));
 
@@ -421,14 +433,14 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         f3 axis = __builtin_fabsf(n.x) > 0.001f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
         f3 tv = normalize3(cross3(axis, n));
         f3 sv = cross3(n, tv);
-        float sinTheta, cosTheta;
-        if (type == 2) {
-            cosTheta = pt_sqrt((1.0f - xi) / (xi * (rough * rough - 1.0f) + 1.0f));
-            sinTheta = pt_sqrt(pt_max(0.0f, 1.0f - cosTheta * cosTheta));
-        } else {
-            sinTheta = pt_sqrt(xi);
-            cosTheta = pt_sqrt(1.0f - xi);
-        }
+        // one sqrt pair for both BRDFs (a wave usually holds both material types): only the
+        // radicands differ -- diffuse: sqrt(xi), sqrt(1-xi); GGX: sqrt((1-xi)/(xi(r^2-1)+1)), then
+        // sqrt(max(0, 1-cos^2))
+        float cos_arg = 1.0f - xi;
+        if (type == 2) cos_arg = cos_arg / (xi * (rough * rough - 1.0f) + 1.0f);
+        const float cosTheta = pt_sqrt(cos_arg);
+        const float sin_arg = type == 2 ? pt_max(0.0f, 1.0f - cosTheta * cosTheta) : xi;
+        const float sinTheta = pt_sqrt(sin_arg);
         f3 a = scale3(scale3(sv, cp), sinTheta);
         f3 b = scale3(scale3(tv, sp), sinTheta);
         f3 c = scale3(n, cosTheta);
@@ -522,7 +534,7 @@ void pt_trace_kernel(const PtTraceParams P)
         __syncthreads();
     }
 
-    PtQueue q = { 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
+    PtQueue q = { 0u, 0u, 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
@@ -544,8 +556,8 @@ void pt_trace_kernel(const PtTraceParams P)
         // ~46 VALU ops of triangle i, so its latency is covered by this wave's own work.
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
-#if PT_TWO_PASS && !PT_TRACK_UV
-        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hidx);
+#if PT_TWO_PASS
+        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
 #if PT_STAMPS
         c_steps += p2steps;
 #else
@@ -566,7 +578,7 @@ void pt_trace_kernel(const PtTraceParams P)
 #endif
 
         PT_STAMP(t2);
-        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED, (PT_TWO_PASS || PT_TRACK_UV)>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #if PT_STAMPS
         PT_STAMP(t3);
         c_regen += t1 - t0; c_loop += t2 - t1; c_shade += t3 - t2; c_iters++;
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void pt_trace_sorted_kernel(const 
     if (tid < 32) (&sh.cnt[0][0])[tid] = 0u;
     __syncthreads();
 
-    PtQueue q = { 0u, 0u, 0u, false };
+    PtQueue q = { 0u, 0u, 0u, 0u, 0u, false };
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void pt_trace_sorted_kernel(const 
             if (i < ntri) pt_tri_test_cull<DET_BOUNDED>(a, i, s.o, s.d, alive, tmax, hu, hv, hidx);
         }
         PT_STAMP(t3);
-        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED, false>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #if PT_STAMPS
         PT_STAMP(t4);
         c_regen += t1 - t0; c_sort += t2 - t1; c_loop += t3 - t2; c_shade += t4 - t3; c_iters++;
