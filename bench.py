@@ -36,6 +36,25 @@ F_ACCEPT, F_SHADE_DIFFUSE, F_SHADE_SPECULAR = 33.0, 120.0, 160.0
 BYTES_PER_SAMPLE = 32.0         # 16 B read + 16 B write of one float4 pixel (GenerateColors.cl:314-321)
 
 
+def pmc_traffic():
+    """HBM bytes per sample from the newest committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json;
+    FETCH_SIZE and WRITE_SIZE collected in separate passes by tools/gpu_pmc.sh and corrected as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read inside the timed run, so the measured
+    per-sample figure is scaled to this launch; None when no PMC summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        d["file"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except (OSError, ValueError):
+        return None
+
+
 def flops_per_ray_from_tallies(st: dict) -> float:
     """Outcome-weighted algorithmic flops per traced ray (intersectWorld + shading)."""
     rays = max(st["rays"], 1)
@@ -190,20 +209,35 @@ def main():
             fpr = flops_per_ray_from_tallies(tallies)
             basis = "outcome-weighted (SURVEY S8d) from the cpu_baseline sample's tallies"
         else:
-            fpr = 36 * 52.0 + 130.0
-            basis = "fallback tri_tests x 52 + 130 shading"
+            # no CPU leg in this run (N > 1 or --no-cpu-baseline): outcome mix of the committed golden
+            # tallies (tests/golden/work_counters.json, oracle, same scene and depth cap 16)
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "work_counters.json")) as f:
+                    fpr = flops_per_ray_from_tallies(json.load(f)["cornell_64x64_f8_d16"])
+                basis = "outcome-weighted (SURVEY S8d) from tests/golden/work_counters.json (cornell_64x64_f8_d16)"
+            except (OSError, KeyError, ValueError):
+                fpr = 36 * 52.0 + 130.0
+                basis = "fallback tri_tests x 52 + 130 shading"
         flops = rank_samples * (F_GEN + F_ACC) + rank_rays * fpr
         tfl = flops / (avg_ms * 1e-3) / 1e12
+        pmc = pmc_traffic()
+        tr_traffic = fo_traffic = None
+        if pmc is not None:
+            tr_traffic = pmc["pt_trace_kernel"]["hbm_bytes_per_sample"] * rank_samples
+            fo_traffic = pmc["pt_fold_kernel"]["hbm_bytes_per_sample"] * rank_samples
         out["roofline"] = {
             "bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
-            "traffic": None, "kernel": "pt_trace_kernel", "avg_launch_ms": avg_ms, "launches": n_launch,
+            "traffic": tr_traffic, "kernel": "pt_trace_kernel", "avg_launch_ms": avg_ms, "launches": n_launch,
             "algorithmic_flops_per_launch": flops, "flops_per_ray": fpr, "flops_basis": basis,
+            "traffic_basis": (pmc["file"] + ": measured HBM bytes/sample x samples of this launch") if pmc else None,
             "note": "FP32 vector-ALU bound, no MFMA (no dense contraction); the f32 MFMA peak equals the VALU peak on gfx950",
         }
         gbs = rank_samples * BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
         out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                               "traffic": None, "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
-                               "note": "reference semantics: 16 B read + 16 B write of the pixel per sample; scene is 3.4 KB"}
+                               "traffic": (tr_traffic + fo_traffic) if pmc else None,
+                               "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
+                               "note": "reference semantics: 16 B read + 16 B write of the pixel per sample; scene is 3.4 KB; "
+                                       "traffic = trace (radiance stores) + fold (radiance reads) kernels"}
         out["kernels"] = {"pt_trace_kernel_ms_total": tot_ms.value, "pt_fold_kernel_ms_total": fold_ms.value,
                           "pt_fold_kernel_launches": int(fold_n.value)}
         if cpu is not None:

@@ -54,11 +54,13 @@ struct PtFoldParams {
     int32_t frame_begin, frame_count;
 };
 
-// det_bound_bits: device word receiving the bit pattern of max_i (|e1|_1 * |e2|_1)
+// det_bound_bits: TWO device words: [0] bit pattern of max_i (|e1|_1 * |e2|_1), [1] number of odd
+// triangles whose e2 is not the exact negation of their predecessor's (0 = the scene is all quads)
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s);
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool sorted, hipStream_t s);
+// quads: ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1 applies)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool quads, bool sorted, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #ifndef PT_DEFAULT_SORTED
 #define PT_DEFAULT_SORTED 0  // which variant PT_OPT_TRACE_VARIANT = 0 (auto) picks

@@ -49,7 +49,15 @@ __global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTria
     // L1 norms; non-negative floats order like their bit patterns, NaN/Inf sort above all finite
     float b = (__builtin_fabsf(e1.x) + __builtin_fabsf(e1.y) + __builtin_fabsf(e1.z)) *
               (__builtin_fabsf(e2.x) + __builtin_fabsf(e2.y) + __builtin_fabsf(e2.z));
-    atomicMax(det_bound_bits, __float_as_uint(b) & 0x7fffffffu);
+    atomicMax(&det_bound_bits[0], __float_as_uint(b) & 0x7fffffffu);
+    // quad structure (pt_quad_pass1): triangle 2k+1 must have e2 == -e2 of triangle 2k.  Numeric
+    // equality, so a zero of either sign matches; a NaN never does.  word 1 counts violations.
+    if (i & 1) {
+        f3 q1 = mk3(raw[i - 1].p1[0], raw[i - 1].p1[1], raw[i - 1].p1[2]);
+        f3 q3 = mk3(raw[i - 1].p3[0], raw[i - 1].p3[1], raw[i - 1].p3[2]);
+        f3 f2 = sub3(q3, q1);
+        if (!(e2.x == -f2.x && e2.y == -f2.y && e2.z == -f2.z)) atomicAdd(&det_bound_bits[1], 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -98,6 +106,9 @@ PTK_DEV PtTriRec pt_load_tri(pt_const_f32p T, int i)
 
 // DET_BOUNDED: the host has verified |e1|*|e2| <= 2e19 for every triangle, so det <= 1e20 and
 // the short exact reciprocal applies to every front-facing triangle.
+#ifndef PT_QUAD_PAIRS
+#define PT_QUAD_PAIRS 1  // use pt_quad_pass1 when the scene is made of (2k, 2k+1) quads
+#endif
 #ifndef PT_TWO_PASS
 #define PT_TWO_PASS 1  // 1: two-pass closest hit (uniform det+u pass, per-lane survivor pass); 0: one flat pass
 #endif
@@ -263,7 +274,33 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
 // (Software-pipelining pass 2 -- fetching the next survivor's record during the current test --
 // was measured slower: 64.8 ms against 61.1 ms; the register copies cost more than the LDS latency
 // that 7 waves per SIMD already hide.)
-template <bool DET_BOUNDED, bool LDS_TABLE>
+// Pass 1 for a QUAD: triangles 2k = (a,b,c) and 2k+1 = (c,d,a) of one quad (RaytraceTest.cpp:186-187)
+// have e2' = a - c = -(c - a) = -e2 exactly, hence pvec' = cross(dir, e2') = -pvec component for
+// component (round-to-nearest is sign-symmetric; only the sign of an exactly-zero component can
+// differ), det' = -(e1'.pvec) and un' = -(tvec'.pvec) with the same magnitudes as the reference's
+// own evaluation.  The conservative bounds of pt_tri_pass1 compare magnitudes only (a zero of either
+// sign passes them), so the second triangle's filter needs no cross product: 14 VALU instead of 20.
+// The host enables this only when EVERY pair (2k, 2k+1) of the scene satisfies e2' == -e2
+// (checked by pt_prep_kernel); returns the two mask bits (bit 0: triangle 2k, bit 1: 2k+1).
+PTK_DEV unsigned pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float bp1z, float be1x, float be1y, float be1z,
+                               const f3& o, const f3& d)
+{
+    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y));
+    float pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z));
+    float pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
+    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
+    float tax = o.x - a.p1x, tay = o.y - a.p1y, taz = o.z - a.p1z;
+    float unA = pt_fma(taz, pvz, pt_fma(tay, pvy, tax * pvx));
+    bool okA = !(unA < -1e-24f) & !(unA > detA * 1.000001f);
+    // second triangle: det' = -q, un' = -r;  !(un' < -1e-24) & !(un' > det' * 1.000001f)
+    float q = pt_fma(be1z, pvz, pt_fma(be1y, pvy, be1x * pvx));
+    float tbx = o.x - bp1x, tby = o.y - bp1y, tbz = o.z - bp1z;
+    float r = pt_fma(tbz, pvz, pt_fma(tby, pvy, tbx * pvx));
+    bool okB = !(r > 1e-24f) & !(r < q * 1.000001f);
+    return (okA ? 1u : 0u) | (okB ? 2u : 0u);
+}
+
+template <bool DET_BOUNDED, bool LDS_TABLE, bool QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx)
 {
@@ -271,15 +308,24 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
     for (int base = 0; base < ntri; base += 32) {
         const int n = ntri - base < 32 ? ntri - base : 32;
         unsigned m = 0u;  // bit j <-> triangle base + j
-        PtTriRec a = pt_load_tri(T, base);
-        int j = 0;
-        for (; j + 1 < n; j += 2) {
-            PtTriRec b = pt_load_tri(T, base + j + 1);
-            m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
-            a = pt_load_tri(T, base + (j + 2 < n ? j + 2 : j + 1));
-            m |= pt_tri_pass1<DET_BOUNDED>(b, o, d) << (j + 1);
+        if (QUADS && DET_BOUNDED) {
+            // ntri is even and every (2k, 2k+1) is a quad; base and n are even
+            for (int j = 0; j < n; j += 2) {
+                const PtTriRec a = pt_load_tri(T, base + j);
+                pt_const_f32p tb = T + 16 * (base + j + 1);
+                m |= pt_quad_pass1(a, tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], o, d) << j;
+            }
+        } else {
+            PtTriRec a = pt_load_tri(T, base);
+            int j = 0;
+            for (; j + 1 < n; j += 2) {
+                PtTriRec b = pt_load_tri(T, base + j + 1);
+                m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
+                a = pt_load_tri(T, base + (j + 2 < n ? j + 2 : j + 1));
+                m |= pt_tri_pass1<DET_BOUNDED>(b, o, d) << (j + 1);
+            }
+            if (j < n) m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
         }
-        if (j < n) m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
         if (!alive) m = 0u;  // a dead lane's stale ray must not cost pass-2 iterations
         // every lane tests its next survivor (index 0 and ok = false once it has none left)
         while (__ballot(m != 0u) != 0ull) {
@@ -515,7 +561,7 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 // LDS_TABLE: the workgroup keeps a copy of the prepared triangle records (stride 12 dwords:
 // conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
 // 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
-template <bool DET_BOUNDED, bool LDS_TABLE>
+template <bool DET_BOUNDED, bool LDS_TABLE, bool QUADS>
 // 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
 // (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
 // makes hipcc keep 94 SGPRs (2 spilled to VGPR lanes): 60.9 -> 59.8 ms.
@@ -557,7 +603,7 @@ void pt_trace_kernel(const PtTraceParams P)
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
 #if PT_TWO_PASS
-        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
+        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
 #if PT_STAMPS
         c_steps += p2steps;
 #else
@@ -838,24 +884,28 @@ __global__ void pt_fill_i32_kernel(int32_t* dst, int32_t value, int n)
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(det_bound_bits, 0, sizeof(unsigned int), s);
+    hipError_t e = hipMemsetAsync(det_bound_bits, 0, 2 * sizeof(unsigned int), s);
     if (e != hipSuccess || ntri <= 0) return e;
     hipLaunchKernelGGL(pt_prep_kernel, dim3((ntri + 255) / 256), dim3(256), 0, s, raw, out, ntri, det_bound_bits);
     return hipGetLastError();
 }
 
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool sorted, hipStream_t s)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool quads, bool sorted, hipStream_t s)
 {
     if (sorted) {
         if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
     } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
         const size_t lds = (size_t)p.ntri * PT_LDS_TRI_STRIDE * sizeof(float);
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (det_bounded && quads && PT_QUAD_PAIRS)
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else if (det_bounded)
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else
+            hipLaunchKernelGGL((pt_trace_kernel<false, true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -895,7 +945,7 @@ int ptk_trace_blocks_per_cu(bool sorted)
 {
     int nb = 0;
     hipError_t e = sorted ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_sorted_kernel<true>, PT_SORT_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true>, PT_TRACE_THREADS, PT_LDS_TRI_MAX * PT_LDS_TRI_STRIDE * sizeof(float));
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, true>, PT_TRACE_THREADS, PT_LDS_TRI_MAX * PT_LDS_TRI_STRIDE * sizeof(float));
     if (e != hipSuccess || nb < 1) nb = sorted ? 1 : 2;
     return nb;
 }

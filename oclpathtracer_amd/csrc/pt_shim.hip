@@ -92,7 +92,8 @@ struct pt_device_s {
     uint64_t prep_version;
     int prep_ntri;
     bool prep_det_bounded;      // scene extent allows the short exact reciprocal
-    unsigned int* det_bound_dev;  // device word written by the prep kernel
+    bool prep_quads;            // every triangle pair (2k, 2k+1) is a quad with e2' == -e2
+    unsigned int* det_bound_dev;  // two device words written by the prep kernel
     // fused-render workspace
     float4* rad;
     size_t rad_bytes;
@@ -198,7 +199,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
-        hipMalloc(&d->det_bound_dev, sizeof(unsigned int)) != hipSuccess) {
+        hipMalloc(&d->det_bound_dev, 2 * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
@@ -609,12 +610,13 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     // wrapped (caller-owned) memory can change behind our back: always re-prepare it
     if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned) return PT_OK;
     HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->det_bound_dev, d->stream));
-    unsigned int bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, d->det_bound_dev, sizeof bits, hipMemcpyDeviceToHost, d->stream));
+    unsigned int words[2] = { 0u, 1u };
+    HIP_TRY(hipMemcpyAsync(words, d->det_bound_dev, sizeof words, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));  // once per scene upload
     float bound;
-    memcpy(&bound, &bits, sizeof bound);
+    memcpy(&bound, &words[0], sizeof bound);
     d->prep_det_bounded = bound <= PT_DET_BOUND_MAX;  // false for NaN / Inf too
+    d->prep_quads = words[1] == 0u && ntri > 0 && (ntri & 1) == 0;
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
@@ -718,7 +720,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, sorted, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, d->prep_quads, sorted, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;

@@ -246,3 +246,45 @@ def test_tonemap_matches_host_f2c(device, cornell):
         dst.release()
     want = scene.f2c(fb[:, :3]).reshape(-1)
     assert np.array_equal(out, want)
+
+
+def _variant_scene(kind):
+    """Scenes that steer the shim into each trace-kernel specialisation."""
+    from oclpathtracer_amd import scene
+
+    tris, mats = scene.load_model()
+    tris = tris.copy()
+    if kind == "quads_scaled":      # still (2k, 2k+1) quads, other numbers: quad filter
+        for f in ("p1", "p2", "p3"):
+            tris[f][:, :3] = tris[f][:, :3] * np.float32(0.73) + np.array([0.11, 0.4, -0.2], np.float32)
+    elif kind == "pairs_broken":    # same triangles, rotated by one: no pair is a quad: generic filter
+        tris = np.roll(tris, 1)
+    elif kind == "odd_count":       # 35 triangles
+        tris = tris[:35].copy()
+    elif kind == "huge_extent":     # |e1||e2| > 2e19: exact-division kernel (DET_BOUNDED = false)
+        for f in ("p1", "p2", "p3"):
+            tris[f][:, :3] = tris[f][:, :3] * np.float32(3.0e10)
+    elif kind == "one_triangle":
+        tris = tris[2:3].copy()
+    elif kind == "degenerate":      # zero-area and NaN triangles among the real ones
+        tris[4]["p2"] = tris[4]["p1"]
+        tris[7]["p3"][:3] = np.nan
+    return tris, mats
+
+
+@pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate"])
+def test_kernel_specialisations_match_oracle(device, oracle, kind):
+    tris, mats = _variant_scene(kind)
+    W, H, frames = 64, 48, 3
+    want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
+    from oclpathtracer_amd.render import Renderer
+
+    r = Renderer(device, tris, mats, W, H, want_stats=True)
+    try:
+        r.render(frames)
+        got = r.read()
+        gst = r.read_stats()
+    finally:
+        r.release()
+    assert_fb_equal(got, want, kind)
+    assert gst["rays"] == st["rays"]
