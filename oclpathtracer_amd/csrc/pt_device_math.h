@@ -86,7 +86,12 @@ PTK_DEV float pt_sqrt(float x)
 // normalize(v) = v * (1.0f / sqrtf(dot(v,v)))   (both correctly rounded)
 PTK_DEV f3 normalize3(f3 a)
 {
-    float inv = pt_rcp(pt_sqrt(dot3(a, a)));
+    // one range check for both short sequences: len2 in [1e-15, 1e30] puts sqrt(len2) in
+    // [3.2e-8, 1e15], inside the reciprocal's exact range [1e-8, 1e20]
+    const float len2 = dot3(a, a);
+    float inv;
+    if (__builtin_expect(len2 >= 1e-15f && len2 <= PTK_SQRT_FAST_MAX, 1)) inv = pt_rcp_fast(pt_sqrt_fast(len2));
+    else inv = 1.0f / __builtin_sqrtf(len2);
     return scale3(a, inv);
 }
 
