@@ -96,7 +96,7 @@ def cpu_baseline(tris, mats, depth, target_seconds=12.0):
     t0 = time.perf_counter()
     ptoracle.render(tris, mats, W, H, 2, max_bounces=depth, nthreads=cores)  # warm-up + calibration
     dt = max(time.perf_counter() - t0, 1e-3)
-    frames = int(max(4, min(512, target_seconds / (dt / 2))))
+    frames = int(max(4, min(4096, target_seconds / (dt / 2))))
     t0 = time.perf_counter()
     _, st = ptoracle.render(tris, mats, W, H, frames, max_bounces=depth, nthreads=cores, want_stats=True)
     dt = time.perf_counter() - t0

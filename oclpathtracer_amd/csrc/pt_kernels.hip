@@ -7,11 +7,14 @@
 //   pt_prep_kernel   once per scene upload: Triangle -> {p1, e1, e2, n, id}
 //   pt_trace_kernel  persistent waves; every LANE owns one path at a time and, when its path
 //                    ends, immediately starts the next (pixel, frame) sample taken from a
-//                    wave-local range of a global batch queue (ballot + mbcnt compaction, no
-//                    LDS).  The 36-triangle closest-hit loop therefore always runs with a full
-//                    exec mask.  Triangle records are wave-uniform: one s_load_dwordx16 each,
-//                    consumed as SGPR operands of the VALU ops (no VGPR/LDS/vector-memory cost).
-//                    Path radiance goes to a staging array rad[frame][pixel].
+//                    wave-local range of a global batch queue (ballot + mbcnt compaction), so
+//                    the closest-hit search always runs with a full exec mask.  The search is
+//                    two-pass: pass 1 walks the triangles with a wave-uniform index (records are
+//                    scalar loads consumed as SGPR operands) and keeps, per lane, a bit mask of
+//                    the triangles that MAY pass the cull and u tests (a cheap conservative
+//                    filter, quad pairs sharing one cross product); pass 2 lets every lane run
+//                    the exact reference test on its own ~3 survivors, fetched per lane from an
+//                    LDS copy of the records.  Path radiance goes to rad[frame][pixel].
 //   pt_fold_kernel   per pixel, in ascending frame order, replays the reference's
 //                    gamma -> mean -> degamma arithmetic (GenerateColors.cl:314-321) over the
 //                    staged radiances: bit-identical to frame-by-frame launches.
