@@ -661,10 +661,16 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
 
     // frames per chunk: radiance staging is 16 B x pixels x frames
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 16);
-    budget = std::min<uint64_t>(budget, (uint64_t)free_b / 2 + d->rad_bytes);
+    // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
+    // take the whole call: a steady-state render loop makes no runtime query at all)
+    uint64_t budget = d->rad_bytes;
+    if ((uint64_t)rp.frame_count * npix * 16 > budget) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 16);
+        budget = std::min<uint64_t>(budget, (uint64_t)free_b / 2 + d->rad_bytes);
+        budget = std::max<uint64_t>(budget, d->rad_bytes);
+    }
     int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 16)));
     if (d->opt_chunk > 0) chunk = (int)std::min<int64_t>(chunk, d->opt_chunk);
     int nchunks = (rp.frame_count + chunk - 1) / chunk;

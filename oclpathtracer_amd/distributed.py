@@ -50,14 +50,17 @@ class StripePlan:
         return max(self.local_rows(r) for r in range(self.world))
 
 
-def gather_slabs(local_slab: torch.Tensor, world: int, rank: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_slabs(local_slab: torch.Tensor, world: int, rank: int, dst: int = 0, group=None,
+                 out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Gather equally-shaped per-rank slabs to ``dst``; returns [world, *slab.shape] there, else None.
 
-    Works with any initialised backend (nccl on GPUs; gloo in the CPU rehearsal tests)."""
+    ``out`` (on ``dst`` only) is an optional preallocated destination.  Works with any initialised
+    backend (nccl on GPUs; gloo in the CPU rehearsal tests)."""
     if world == 1:
         return local_slab.unsqueeze(0)
     if rank == dst:
-        out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
+        if out is None:
+            out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
         dist.gather(local_slab, [out[i] for i in range(world)], dst=dst, group=group)
         return out
     dist.gather(local_slab, None, dst=dst, group=group)
@@ -81,9 +84,16 @@ class StripeImage:
                                  stripe_rows=stripe_rows, fb_device_ptr=self.local.data_ptr(), want_stats=want_stats)
         assert self.renderer.local_rows == self.plan.local_rows(rank)
         self.image = None
-        self._gbuf = self._ibuf = None
+        self._slabs = self._gbuf = self._ibuf = None
         if rank == 0 and world > 1:
+            # gather destination and assembled image live for the object's lifetime: a render loop
+            # allocates, wraps and synchronises nothing per step
             self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=self.cuda)
+            self._slabs = torch.empty((self.world, self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
+            self._gbuf = adl.Buffer(dtype=adl.float4)
+            self._ibuf = adl.Buffer(dtype=adl.float4)
+            self._gbuf.setRawPtr(dev, self._slabs.data_ptr(), self._slabs.numel() // 4)
+            self._ibuf.setRawPtr(dev, self.image.data_ptr(), self.image.numel() // 4)
 
     def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> None:
         self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces)
@@ -93,21 +103,11 @@ class StripeImage:
         if self.world == 1:
             self.image = self.local[: self.height]
             return self.image
-        slabs = gather_slabs(self.local, self.world, self.rank)
+        gather_slabs(self.local, self.world, self.rank, out=self._slabs)
         if self.rank != 0:
             return None
-        lib = shim.load()
-        g = adl.Buffer(dtype=adl.float4)
-        i = adl.Buffer(dtype=adl.float4)
-        g.setRawPtr(self.dev, slabs.data_ptr(), slabs.numel() // 4)
-        i.setRawPtr(self.dev, self.image.data_ptr(), self.image.numel() // 4)
-        try:
-            shim.check(lib.pt_assemble_stripes(self.dev._h, g._h, i._h, self.width, self.height, self.plan.stripe_rows,
-                                               self.world, self.plan.slab_rows, None))
-        finally:
-            # buffer release synchronises the stream, so `slabs` may be dropped afterwards
-            g.release()
-            i.release()
+        shim.check(shim.load().pt_assemble_stripes(self.dev._h, self._gbuf._h, self._ibuf._h, self.width, self.height,
+                                                   self.plan.stripe_rows, self.world, self.plan.slab_rows, None))
         return self.image
 
     def reset_stats(self) -> None:
@@ -119,4 +119,8 @@ class StripeImage:
         return self.renderer.read_stats()
 
     def release(self) -> None:
+        for b in (self._gbuf, self._ibuf):
+            if b is not None:
+                b.release()
+        self._gbuf = self._ibuf = None
         self.renderer.release()
