@@ -156,7 +156,17 @@ PTK_DEV void pt_sincos(float phi, float& s_out, float& c_out)
 }
 
 // ---- pow(x, y): y == 2 -> x*x ; else exp2(y*log2(x)) in binary64, one rounding -------------
-PTK_DEV float pt_pow(float x, float y)
+// Two 128-entry tables, no division (PTSPEC, mirrored by oracle/pt_oracle.c):
+//   log2: m in [1,2), i = top 7 fraction bits, c_i ~ 1/(1+(i+.5)/128) with 16 significant bits so
+//         that r = m*c_i - 1 is EXACT;  log2(x) = (e - log2 c_i) + r*(A1 + r*(A2 + ... + r*A6))
+//   exp2: t = q + j/128 + f, |f| <= 2^-8;  2^t = 2^q * T_j * (1 + f*(B1 + f*(B2 + ... + f*B5)))
+// The tables live in device memory (below); kernels that call pt_pow in a loop stage them in LDS
+// and pass the LDS pointers.
+__device__ const double pt_pow_logc_tab[128] = PTK_POW_LOGC_INIT;
+__device__ const double pt_pow_logl_tab[128] = PTK_POW_LOGL_INIT;
+__device__ const double pt_pow_exp2_tab[128] = PTK_POW_EXP2_INIT;
+
+PTK_DEV float pt_pow(float x, float y, const double* logc, const double* logl, const double* exp2t)
 {
     if (y == 2.0f) return x * x;
     if (!(x > 0.0f)) {
@@ -167,42 +177,35 @@ PTK_DEV float pt_pow(float x, float y)
     double xd = (double)x;
     uint64_t bits = (uint64_t)__double_as_longlong(xd);
     int e = (int)(bits >> 52) - 1023;
+    int idx = (int)(bits >> 45) & 127;
     bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
     double m = __longlong_as_double((long long)bits);
-    if (m > PTK_SQRT2) { m = m * 0.5; e = e + 1; }
-    double s = (m - 1.0) / (m + 1.0);
-    double s2 = s * s;
-    double p = PTK_LOG2_L8;
-    p = pt_fmad(p, s2, PTK_LOG2_L7);
-    p = pt_fmad(p, s2, PTK_LOG2_L6);
-    p = pt_fmad(p, s2, PTK_LOG2_L5);
-    p = pt_fmad(p, s2, PTK_LOG2_L4);
-    p = pt_fmad(p, s2, PTK_LOG2_L3);
-    p = pt_fmad(p, s2, PTK_LOG2_L2);
-    p = pt_fmad(p, s2, PTK_LOG2_L1);
-    p = pt_fmad(p, s2, PTK_LOG2_L0);
-    double l = pt_fmad(s, p, (double)e);
+    double r = pt_fmad(m, logc[idx], -1.0);
+    double p = PTK_LOG2_A6;
+    p = pt_fmad(p, r, PTK_LOG2_A5);
+    p = pt_fmad(p, r, PTK_LOG2_A4);
+    p = pt_fmad(p, r, PTK_LOG2_A3);
+    p = pt_fmad(p, r, PTK_LOG2_A2);
+    p = pt_fmad(p, r, PTK_LOG2_A1);
+    double l = pt_fmad(r, p, (double)e + logl[idx]);
     double t = (double)y * l;
     if (t >= 130.0) return __builtin_inff();
     if (t <= -160.0) return 0.0f;
-    int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
-    double f = t - (double)k;
-    double q = PTK_EXP2_E12;
-    q = pt_fmad(q, f, PTK_EXP2_E11);
-    q = pt_fmad(q, f, PTK_EXP2_E10);
-    q = pt_fmad(q, f, PTK_EXP2_E9);
-    q = pt_fmad(q, f, PTK_EXP2_E8);
-    q = pt_fmad(q, f, PTK_EXP2_E7);
-    q = pt_fmad(q, f, PTK_EXP2_E6);
-    q = pt_fmad(q, f, PTK_EXP2_E5);
-    q = pt_fmad(q, f, PTK_EXP2_E4);
-    q = pt_fmad(q, f, PTK_EXP2_E3);
-    q = pt_fmad(q, f, PTK_EXP2_E2);
-    q = pt_fmad(q, f, PTK_EXP2_E1);
-    q = pt_fmad(q, f, PTK_EXP2_E0);
-    uint64_t sb = (uint64_t)(int64_t)(k + 1023) << 52;
+    int ki = (int)(t * 128.0 + (t < 0.0 ? -0.5 : 0.5));
+    double f = pt_fmad(-(double)ki, 0x1p-7, t);
+    int j = ki & 127;
+    int q = (ki - j) >> 7;
+    double g = PTK_EXP2_B5;
+    g = pt_fmad(g, f, PTK_EXP2_B4);
+    g = pt_fmad(g, f, PTK_EXP2_B3);
+    g = pt_fmad(g, f, PTK_EXP2_B2);
+    g = pt_fmad(g, f, PTK_EXP2_B1);
+    double w = f * g;
+    double T = exp2t[j];
+    double res = pt_fmad(T, w, T);
+    uint64_t sb = (uint64_t)(int64_t)(q + 1023) << 52;
     double sc = __longlong_as_double((long long)sb);
-    return (float)(q * sc);
+    return (float)(res * sc);
 }
 
 #define PTK_TWO_PI 6.28318530718f

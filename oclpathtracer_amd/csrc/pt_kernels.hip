@@ -510,7 +510,8 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
             float dwon = dot3(wo, n);
             if (!(dwin * dwon < 0.0f)) {
                 float r2 = rough * rough;
-                float D = r2 * PTK_INV_PI / pt_pow(cosTheta * cosTheta * (r2 - 1.0f) + 1.0f, 2.0f);
+                const float gd = cosTheta * cosTheta * (r2 - 1.0f) + 1.0f;
+                float D = r2 * PTK_INV_PI / (gd * gd);  // pow(x, 2.0f) is x*x in PTSPEC (:177)
                 pdf = D * cosTheta / (4.0f * dot3(wo, sdir));
                 float g = D / (4.0f * dwin * dwon);
                 color = mk3(alb.x * g * 2.0f, alb.y * g * 2.0f, alb.z * g * 2.0f);
@@ -808,6 +809,16 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void pt_trace_sorted_kernel(const 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
 {
+    // the three pow tables (3 KiB) in LDS: per-lane indices, read 6 x per sample
+    __shared__ double tab[3][128];
+    for (int k = (int)threadIdx.x; k < 384; k += 256) {
+        int w = k >> 7, i = k & 127;
+        tab[w][i] = w == 0 ? pt_pow_logc_tab[i] : w == 1 ? pt_pow_logl_tab[i] : pt_pow_exp2_tab[i];
+    }
+    __syncthreads();
+    const double* LC = tab[0];
+    const double* LL = tab[1];
+    const double* ET = tab[2];
     unsigned lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= P.npix_local) return;
     const float inv_gamma = 1.0f / PTK_GAMMA;
@@ -820,15 +831,15 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
     for (int f = 0; f < P.frame_count; ++f, ++z) {
         float4 c = P.rad[(size_t)f * P.npix_local + lp];
         if (z == 0) {
-            mx = pt_pow(c.x, inv_gamma);
-            my = pt_pow(c.y, inv_gamma);
-            mz = pt_pow(c.z, inv_gamma);
+            mx = pt_pow(c.x, inv_gamma, LC, LL, ET);
+            my = pt_pow(c.y, inv_gamma, LC, LL, ET);
+            mz = pt_pow(c.z, inv_gamma, LC, LL, ET);
         } else {
             float zm1 = (float)(z - 1), zf = (float)z;
-            float ox = pt_pow(mx, PTK_GAMMA), oy = pt_pow(my, PTK_GAMMA), oz = pt_pow(mz, PTK_GAMMA);
-            mx = pt_pow((ox * zm1 + c.x) / zf, inv_gamma);
-            my = pt_pow((oy * zm1 + c.y) / zf, inv_gamma);
-            mz = pt_pow((oz * zm1 + c.z) / zf, inv_gamma);
+            float ox = pt_pow(mx, PTK_GAMMA, LC, LL, ET), oy = pt_pow(my, PTK_GAMMA, LC, LL, ET), oz = pt_pow(mz, PTK_GAMMA, LC, LL, ET);
+            mx = pt_pow((ox * zm1 + c.x) / zf, inv_gamma, LC, LL, ET);
+            my = pt_pow((oy * zm1 + c.y) / zf, inv_gamma, LC, LL, ET);
+            mz = pt_pow((oz * zm1 + c.z) / zf, inv_gamma, LC, LL, ET);
         }
     }
     if (P.frame_count > 0) P.fb[lp] = make_float4(mx, my, mz, 1.0f);

@@ -33,7 +33,8 @@
  *   - normalize(v) = v * (1.0f / sqrtf(dot(v,v)))
  *   - max(a,b)   = (a < b) ? b : a            (OpenCL's formula; NaN in a is returned)
  *   - sin, cos   : double-precision Cody-Waite + Taylor evaluation, rounded once to float
- *   - pow(x,y)   : y == 2 -> x*x ; else exp2(y*log2(x)) evaluated in double, rounded once
+ *   - pow(x,y)   : y == 2 -> x*x ; else exp2(y*log2(x)) evaluated in double (two 128-entry
+ *                  tables, no division), rounded once
  *   - tan(0.5f*fov) is the constant 0x1.279a74p-1f (correctly rounded)
  *   - the w lane of radiance/mask is dropped (never observable: GenerateColors.cl:293,299)
  */
@@ -157,7 +158,17 @@ PTOR_INLINE void ptor_sincos(float phi, float* s_out, float* c_out)
 }
 
 /* pow(x, y) for the two uses of the path: y == 2 (GGX denominator, :177) and the gamma
- * exponents 2.2f and 1/2.2f (:292,:298), y > 0. */
+ * exponents 2.2f and 1/2.2f (:292,:298), y > 0.
+ * exp2(y * log2(x)) in binary64 with two 128-entry tables (no division, short polynomials):
+ *   log2: m in [1,2) (exact binary64 image of the binary32 significand), i = its top 7 fraction
+ *         bits, c_i ~ 1/(1+(i+.5)/128) with 16 significant bits  =>  r = m*c_i - 1 EXACT, |r| < 2^-7;
+ *         log2(x) = (e - log2(c_i)) + r*(A1 + r*(A2 + ... + r*A6))
+ *   exp2: t = q + j/128 + f, |f| <= 2^-8;  2^t = 2^q * T_j * (1 + f*(B1 + f*(B2 + ... + f*B5)))
+ * Truncation < 1e-17; the result is rounded once to binary32. */
+static const double ptor_pow_logc[128] = PTOR_POW_LOGC_INIT;
+static const double ptor_pow_logl[128] = PTOR_POW_LOGL_INIT;
+static const double ptor_pow_exp2[128] = PTOR_POW_EXP2_INIT;
+
 PTOR_INLINE float ptor_pow(float x, float y)
 {
     if (y == 2.0f) return x * x;
@@ -170,44 +181,37 @@ PTOR_INLINE float ptor_pow(float x, float y)
     uint64_t bits;
     memcpy(&bits, &xd, 8);
     int e = (int)(bits >> 52) - 1023;
+    int idx = (int)(bits >> 45) & 127;
     bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
     double m;
     memcpy(&m, &bits, 8);
-    if (m > PTOR_SQRT2) { m = m * 0.5; e = e + 1; }
-    double s = (m - 1.0) / (m + 1.0);
-    double s2 = s * s;
-    double p = PTOR_LOG2_L8;
-    p = ptor_fmad(p, s2, PTOR_LOG2_L7);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L6);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L5);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L4);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L3);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L2);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L1);
-    p = ptor_fmad(p, s2, PTOR_LOG2_L0);
-    double l = ptor_fmad(s, p, (double)e); /* log2(x) */
+    double r = ptor_fmad(m, ptor_pow_logc[idx], -1.0);
+    double p = PTOR_LOG2_A6;
+    p = ptor_fmad(p, r, PTOR_LOG2_A5);
+    p = ptor_fmad(p, r, PTOR_LOG2_A4);
+    p = ptor_fmad(p, r, PTOR_LOG2_A3);
+    p = ptor_fmad(p, r, PTOR_LOG2_A2);
+    p = ptor_fmad(p, r, PTOR_LOG2_A1);
+    double l = ptor_fmad(r, p, (double)e + ptor_pow_logl[idx]); /* log2(x) */
     double t = (double)y * l;
     if (t >= 130.0) return __builtin_inff();
     if (t <= -160.0) return 0.0f;
-    int k = (int)(t + (t < 0.0 ? -0.5 : 0.5)); /* round half away; |k| <= 160 */
-    double f = t - (double)k;                  /* exact, |f| <= 0.5 */
-    double q = PTOR_EXP2_E12;
-    q = ptor_fmad(q, f, PTOR_EXP2_E11);
-    q = ptor_fmad(q, f, PTOR_EXP2_E10);
-    q = ptor_fmad(q, f, PTOR_EXP2_E9);
-    q = ptor_fmad(q, f, PTOR_EXP2_E8);
-    q = ptor_fmad(q, f, PTOR_EXP2_E7);
-    q = ptor_fmad(q, f, PTOR_EXP2_E6);
-    q = ptor_fmad(q, f, PTOR_EXP2_E5);
-    q = ptor_fmad(q, f, PTOR_EXP2_E4);
-    q = ptor_fmad(q, f, PTOR_EXP2_E3);
-    q = ptor_fmad(q, f, PTOR_EXP2_E2);
-    q = ptor_fmad(q, f, PTOR_EXP2_E1);
-    q = ptor_fmad(q, f, PTOR_EXP2_E0);
-    uint64_t sb = (uint64_t)(int64_t)(k + 1023) << 52; /* 2^k as a double, k in [-160,130] */
+    int ki = (int)(t * 128.0 + (t < 0.0 ? -0.5 : 0.5)); /* round(128 t), half away from zero */
+    double f = ptor_fmad(-(double)ki, 0x1p-7, t);       /* |f| <= 2^-8 */
+    int j = ki & 127;
+    int q = (ki - j) >> 7; /* ki - j is a multiple of 128: the shift is exact for either sign */
+    double g = PTOR_EXP2_B5;
+    g = ptor_fmad(g, f, PTOR_EXP2_B4);
+    g = ptor_fmad(g, f, PTOR_EXP2_B3);
+    g = ptor_fmad(g, f, PTOR_EXP2_B2);
+    g = ptor_fmad(g, f, PTOR_EXP2_B1);
+    double w = f * g; /* 2^f - 1 */
+    double T = ptor_pow_exp2[j];
+    double res = ptor_fmad(T, w, T);
+    uint64_t sb = (uint64_t)(int64_t)(q + 1023) << 52; /* 2^q as a double, q in [-161, 130] */
     double sc;
     memcpy(&sc, &sb, 8);
-    return (float)(q * sc); /* one rounding to float (overflow -> inf, subnormal floats exact) */
+    return (float)(res * sc); /* one rounding to float (overflow -> inf, subnormal floats exact) */
 }
 
 /* ------------------------------------------------------------------ rays (GenerateColors.cl:73-87, 263-288) */
