@@ -886,6 +886,21 @@ __global__ void pt_tonemap_kernel(const float4* __restrict__ fb, int32_t* __rest
     rgb[3 * i + 2] = pt_f2c(v.z);
 }
 
+// PTSPEC transcendentals on arrays, for direct device-vs-oracle parity tests:
+// out[4i] = sin(in[i]), cos(in[i]), pow(in[i], 2.2f), pow(in[i], 1/2.2f)
+__global__ void pt_math_kernel(const float* __restrict__ in, float* __restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = in[i];
+    float s = 0.0f, c = 0.0f;
+    if (x >= 0.0f && x <= 8.0f) pt_sincos(x, s, c);  // PTSPEC defines sin/cos for phi in [0, 2 pi]
+    out[4 * i + 0] = s;
+    out[4 * i + 1] = c;
+    out[4 * i + 2] = pt_pow(x, PTK_GAMMA, pt_pow_logc_tab, pt_pow_logl_tab, pt_pow_exp2_tab);
+    out[4 * i + 3] = pt_pow(x, 1.0f / PTK_GAMMA, pt_pow_logc_tab, pt_pow_logl_tab, pt_pow_exp2_tab);
+}
+
 __global__ void pt_fill_i32_kernel(int32_t* dst, int32_t value, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -945,6 +960,13 @@ hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStrea
 {
     if (npix == 0) return hipSuccess;
     hipLaunchKernelGGL(pt_tonemap_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, fb, rgb, npix);
+    return hipGetLastError();
+}
+
+hipError_t ptk_math(const float* in, float* out, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ extern "C" int pt_abi_version(void) { return PT_SHIM_ABI_VERSION; }
 // ------------------------------------------------------------------------------------------
 // objects
 // ------------------------------------------------------------------------------------------
-enum { KERNEL_GENERATE_COLORS = 0, KERNEL_FILL = 1, KERNEL_COUNT = 2 };
+enum { KERNEL_GENERATE_COLORS = 0, KERNEL_FILL = 1, KERNEL_MATH = 2, KERNEL_COUNT = 3 };
 
 struct pt_kernel_s {
     int id;
@@ -198,6 +198,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_variant = 0;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
+    d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc(&d->det_bound_dev, 2 * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
@@ -954,6 +955,20 @@ static int launch_fill(pt_device_s* d, const pt_launch_arg* a, int nargs, long l
     return event_end(d, ev);
 }
 
+static int launch_math(pt_device_s* d, const pt_launch_arg* a, int nargs, long long n, pt_event_s* ev)
+{
+    // MathKernel(const float* in, float* out): out[4i..4i+3] = sin, cos, pow(.,2.2f), pow(.,1/2.2f) of in[i]
+    if (nargs != 2 || !a[0].is_buffer || !a[1].is_buffer) return fail(PT_ERR_ARGS, "MathKernel expects (buffer, buffer)");
+    pt_buffer_s *in = a[0].buffer, *out = a[1].buffer;
+    if (!in || !out || in->dev != d || out->dev != d) return fail(PT_ERR_ARGS, "MathKernel: bad buffer");
+    long long cnt = std::min<long long>(n, std::min<long long>((long long)(in->bytes / 4), (long long)(out->bytes / 16)));
+    int rc = flush_pending(d);
+    if (rc || (rc = event_begin(d, ev))) return rc;
+    HIP_TRY(ptk_math((const float*)in->dptr, (float*)out->dptr, (int)std::min<long long>(cnt, 0x7fffffff), d->stream));
+    out->version++;
+    return event_end(d, ev);
+}
+
 extern "C" int pt_launch_2d(pt_device_t d, pt_kernel_t k, const pt_launch_arg* args, int nargs, int ntx, int nty, int lx,
                             int ly, pt_event_t ev, float* ms_out)
 {
@@ -971,6 +986,7 @@ extern "C" int pt_launch_2d(pt_device_t d, pt_kernel_t k, const pt_launch_arg* a
     switch (k->id) {
     case KERNEL_GENERATE_COLORS: return launch_generate_colors(d, args, nargs, n, ev, ms_out);
     case KERNEL_FILL: return launch_fill(d, args, nargs, n, ev);
+    case KERNEL_MATH: return launch_math(d, args, nargs, n, ev);
     default: return fail(PT_ERR_NOT_FOUND, "unknown kernel id");
     }
 }
