@@ -109,6 +109,9 @@ PTK_DEV PtTriRec pt_load_tri(pt_const_f32p T, int i)
 
 // DET_BOUNDED: the host has verified |e1|*|e2| <= 2e19 for every triangle, so det <= 1e20 and
 // the short exact reciprocal applies to every front-facing triangle.
+#ifndef PT_VALIDATE_FILTER
+#define PT_VALIDATE_FILTER 0  // diagnostic: check the pass-1 filter against the reference predicate
+#endif
 #ifndef PT_QUAD_PAIRS
 #define PT_QUAD_PAIRS 1  // use pt_quad_pass1 when the scene is made of (2k, 2k+1) quads
 #endif
@@ -305,8 +308,10 @@ PTK_DEV unsigned pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float 
 
 template <bool DET_BOUNDED, bool LDS_TABLE, bool QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
-                                       bool alive, float& tmax, float& hu, float& hv, int& hidx)
+                                       bool alive, float& tmax, float& hu, float& hv, int& hidx,
+                                       unsigned long long* vstat = nullptr)
 {
+    (void)vstat;
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
     for (int base = 0; base < ntri; base += 32) {
         const int n = ntri - base < 32 ? ntri - base : 32;
@@ -329,6 +334,30 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             }
             if (j < n) m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
         }
+#if PT_VALIDATE_FILTER
+        // DIAGNOSTIC build (tools/validate_filter.py): the reference predicate of :100 and :109,
+        // evaluated literally with IEEE division, must never accept a pair the filter dropped
+        if (alive && vstat) {
+            unsigned mx = 0u;
+            for (int jj = 0; jj < n; ++jj) {
+                const PtTriRec r = pt_load_tri(T, base + jj);
+                float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+                float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+                float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+                float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+                bool keep = !(det < 1e-8f || -det > 1e-8f);
+                float inv_det = 1.0f / det;
+                float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+                float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+                keep = keep && !(u < 0.0f || u > 1.0f);
+                mx |= (keep ? 1u : 0u) << jj;
+            }
+            atomicAdd(&vstat[0], (unsigned long long)n);                 // pairs examined
+            atomicAdd(&vstat[1], (unsigned long long)__popc(mx));        // pairs the reference keeps
+            atomicAdd(&vstat[2], (unsigned long long)__popc(m));         // pairs the filter keeps
+            atomicAdd(&vstat[3], (unsigned long long)__popc(mx & ~m));   // VIOLATIONS: must stay 0
+        }
+#endif
         if (!alive) m = 0u;  // a dead lane's stale ray must not cost pass-2 iterations
         // every lane tests its next survivor (index 0 and ok = false once it has none left)
         while (__ballot(m != 0u) != 0ull) {
@@ -607,7 +636,8 @@ void pt_trace_kernel(const PtTraceParams P)
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
 #if PT_TWO_PASS
-        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
+        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
+                                                                                          PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr);
 #if PT_STAMPS
         c_steps += p2steps;
 #else

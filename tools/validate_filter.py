@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic: empirical check of the pass-1 conservative filter (needs the PT_VALIDATE_FILTER=1
+build).  For every (ray, triangle) pair actually traced, the reference's predicate of
+GenerateColors.cl:100,109 (literal form, IEEE division) is evaluated beside the filter; a pair the
+reference keeps but the filter dropped is a VIOLATION and must never occur.
+usage: PT_SHIM_LIB=.../libptshim_validate.so python tools/validate_filter.py [scene] [W H spp]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oclpathtracer_amd import adl, scene, shim
+from oclpathtracer_amd.render import Renderer
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+W, H, spp = (int(x) for x in (sys.argv[2:5] + ["512", "512", "64"][len(sys.argv[2:5]):]))
+t, m = scene.load_model()
+if kind == "rolled":          # pairs broken: per-triangle filter
+    t = np.roll(t, 1)
+elif kind == "soup":
+    t, m = scene.make_soup(200)
+elif kind == "scaled":
+    t = t.copy()
+    for f in ("p1", "p2", "p3"):
+        t[f][:, :3] = t[f][:, :3] * np.float32(37.5) + np.array([3.0, -80.0, 11.0], np.float32)
+assert adl.init()
+dev = adl.DeviceUtils.allocate()
+r = Renderer(dev, t, m, W, H, want_stats=True)
+r.render(spp)
+out = np.zeros(shim.PT_STAT_WORDS, np.uint64)
+r.stats.read(out, shim.PT_STAT_WORDS); dev.waitForCompletion()
+samples, rays, pairs, ref_keep, flt_keep, viol = (int(x) for x in out[:6])
+print("%-8s %dx%d x %d: %d rays, %.4g pairs examined; reference keeps %.3f%%, filter keeps %.3f%%; VIOLATIONS: %d"
+      % (kind, W, H, spp, rays, pairs, 100.0 * ref_keep / max(pairs, 1), 100.0 * flt_keep / max(pairs, 1), viol))
+r.release(); adl.DeviceUtils.deallocate(dev)
+sys.exit(1 if viol else 0)
