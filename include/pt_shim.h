@@ -104,7 +104,12 @@ enum pt_option {
     /* which trace kernel renders: 0 = library default, 1 = lane-regenerating waves,
      * 2 = octant-sorted workgroups (rays regrouped by direction octant through LDS every bounce).
      * All variants produce identical pixels. */
-    PT_OPT_TRACE_VARIANT = 3
+    PT_OPT_TRACE_VARIANT = 3,
+    /* conservative pass-1 filter of the closest-hit search, for A/B timing and parity tests:
+     * 0 = the strongest the uploaded scene allows, 1 = independent triangles, 2 = at most the
+     * pair filter (shared cross product), 3 = at most the shared-u filter (one numerator decides
+     * both triangles of an (a,b,c),(c,d,a) pair).  All settings produce identical pixels. */
+    PT_OPT_QUAD_FILTER = 4
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

@@ -45,6 +45,8 @@ struct PtTraceParams {
     int32_t stripe_rows, n_ranks, rank;
     uint32_t npix_local;
     uint32_t batches_per_frame, total_batches;
+    float quad_delta1;            // quad mode 2 (pt_quad2_pass1): slack of the shared-u bounds
+    float ray_radius;             // quad mode 2: rays with |origin - eye|_inf above this keep every triangle
 };
 
 struct PtFoldParams {
@@ -54,13 +56,20 @@ struct PtFoldParams {
     int32_t frame_begin, frame_count;
 };
 
-// det_bound_bits: TWO device words: [0] bit pattern of max_i (|e1|_1 * |e2|_1), [1] number of odd
-// triangles whose e2 is not the exact negation of their predecessor's (0 = the scene is all quads)
+// det_bound_bits: FOUR device words: [0] bit pattern of max_i (|e1|_1 * |e2|_1), [1] number of odd
+// triangles whose e2 is not the exact negation of their predecessor's (0 = the scene is all quads),
+// [2] bit pattern of max |vertex - eye|_inf, [3] number of odd triangles whose p1 is not their
+// predecessor's p3 (0 = every pair is (a,b,c),(c,d,a))
+#define PT_PREP_WORDS 4
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s);
+// quad mode 2: writes every odd record's pad0[0] = slack of its shared-u bound (needs the scene
+// diameter bound D from word [2] of the first pass, hence a second tiny launch)
+hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, hipStream_t s);
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
-// quads: ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1 applies)
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool quads, bool sorted, hipStream_t s);
+// quads: 0 = none; 1 = ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1);
+//        2 = additionally p1' == p3 and the margins are prepared (pt_quad2_pass1)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #ifndef PT_DEFAULT_SORTED
 #define PT_DEFAULT_SORTED 0  // which variant PT_OPT_TRACE_VARIANT = 0 (auto) picks

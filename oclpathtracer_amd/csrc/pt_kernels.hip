@@ -26,6 +26,11 @@
 
 typedef const __attribute__((address_space(4))) float* pt_const_f32p;  // scalar (SMEM) loads
 
+// camera position, GenerateColors.cl:265
+#define PT_EYE_X 0.0f
+#define PT_EYE_Y 2.75f
+#define PT_EYE_Z 4.0f
+
 // ------------------------------------------------------------------------------------------
 // scene preparation
 // ------------------------------------------------------------------------------------------
@@ -60,7 +65,37 @@ __global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTria
         f3 q3 = mk3(raw[i - 1].p3[0], raw[i - 1].p3[1], raw[i - 1].p3[2]);
         f3 f2 = sub3(q3, q1);
         if (!(e2.x == -f2.x && e2.y == -f2.y && e2.z == -f2.z)) atomicAdd(&det_bound_bits[1], 1u);
+        // (a,b,c),(c,d,a): this triangle starts at its predecessor's third vertex (pt_quad2_pass1)
+        if (!(p1.x == q3.x && p1.y == q3.y && p1.z == q3.z)) atomicAdd(&det_bound_bits[3], 1u);
     }
+    // scene radius about the camera position (GenerateColors.cl:265), for pt_quad2_pass1's error bound
+    float r = 0.0f;
+    const f3 vs[3] = { p1, p2, p3 };
+    for (int k = 0; k < 3; ++k) {
+        float ax = __builtin_fabsf(vs[k].x - PT_EYE_X), ay = __builtin_fabsf(vs[k].y - PT_EYE_Y), az = __builtin_fabsf(vs[k].z - PT_EYE_Z);
+        r = !(ax <= r) ? ax : r;  // a NaN replaces r and then sticks (every later "<=" is false too)
+        r = !(ay <= r) ? ay : r;
+        r = !(az <= r) ? az : r;
+    }
+    atomicMax(&det_bound_bits[2], __float_as_uint(r) & 0x7fffffffu);
+}
+
+// Second pass of the scene preparation for quad mode 2 (see pt_quad2_pass1 for the derivation):
+// record 2k+1 gets pad0[0] = delta3 = slack of the lower bound of its shared-u test.
+//   delta2 = |e1' + e1|_2 |e2|_2 (how far the pair is from a parallelogram) + 128 u D^2
+//   delta3 = delta2 * c + delta1
+// every factor inflated by 0.1 % to cover the rounding of this very computation.
+__global__ void pt_prep_quad_margins_kernel(PtPrepTriangle* __restrict__ out, int ntri, float diameter, float delta1)
+{
+    int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x) + 1;
+    if (i >= ntri) return;
+    const PtPrepTriangle a = out[i - 1], b = out[i];
+    float wx = b.e1[0] + a.e1[0], wy = b.e1[1] + a.e1[1], wz = b.e1[2] + a.e1[2];
+    float wn = __builtin_sqrtf(wx * wx + wy * wy + wz * wz) * 1.001f;
+    float en = __builtin_sqrtf(a.e2[0] * a.e2[0] + a.e2[1] * a.e2[1] + a.e2[2] * a.e2[2]) * 1.001f;
+    float delta2 = wn * en * 1.001f + 128.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
+    float delta3 = (delta2 * 1.00001f + delta1) * 1.001f;
+    out[i].pad0[0] = delta3;  // +Inf / NaN keep every second triangle of the pair: valid, merely slow
 }
 
 // ------------------------------------------------------------------------------------------
@@ -72,7 +107,7 @@ PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& se
     float aspectratio = (float)width / (float)height;
     float angle = PTK_TAN_HALF_FOV;
 
-    const f3 eye = mk3(0.0f, 2.75f, 4.0f);
+    const f3 eye = mk3(PT_EYE_X, PT_EYE_Y, PT_EYE_Z);
     const f3 center = add3(eye, mk3(0.0f, 0.0f, -1.0f));
     const f3 up = mk3(0.0f, 1.0f, 0.0f);
     const f3 viewDir = normalize3(sub3(center, eye));
@@ -196,8 +231,23 @@ PTK_DEV void pt_hit_uv(const PtPrepTriangle* tris, int hidx, const f3& o, const 
 // Exactness: a pair that fails :100 or :109 can never be accepted, the survivors are tested with
 // the same operations on the same operands, in the same (ascending) order, against the same
 // running tmax -- the accepted (t, index) are those of the one-pass loop bit for bit.
+// Survivor masks are built MSB-first: m = 2 m + flag is ONE v_addc_co_u32 whose carry-in is the
+// comparison's own lane mask (against v_cndmask + v_lshl_or per flag).  After the n flags of a
+// chunk, triangle j of the chunk sits at bit n-1-j: pass 2 walks the mask from its highest bit.
+// Flags travel as the comparisons' lane masks (ballot of a single compare IS the v_cmp result;
+// the conjunction is then an s_and_b64), never as per-lane booleans.
+typedef unsigned long long pt_lanes;
+#define PT_LANES(cond) __builtin_amdgcn_ballot_w64(cond)
+PTK_DEV unsigned pt_push_flag(unsigned m, pt_lanes c)
+{
+    unsigned long long carry_out;
+    unsigned r;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(c));
+    return r;
+}
+
 template <bool DET_BOUNDED>
-PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
+PTK_DEV pt_lanes pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
 {
     float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
     float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
@@ -205,7 +255,7 @@ PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
     float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
     float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
     float un = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx));  // u = un * RN(1/det)
-    bool ok;
+    pt_lanes ok;
     if (DET_BOUNDED) {
         // Pass 2 re-applies :100 and :109 exactly, so pass 1 only has to keep a SUPERSET of the
         // pairs that pass them -- without the reciprocal (a quarter-rate instruction + 2 fma).
@@ -215,12 +265,12 @@ PTK_DEV unsigned pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
         // A NaN in det or un fails every "<"/">" here and stays in the mask, as it passes
         // :100/:109 in the reference.  The cull test (:100) itself is left to pass 2: a pair with
         // det < 1e-8 survives these two bounds only for det in [-1e-24, 1e-8), which is rare.
-        ok = !(un < -1e-24f) & !(un > det * 1.000001f);
+        ok = PT_LANES(!(un < -1e-24f)) & PT_LANES(!(un > det * 1.000001f));
     } else {
         float u = un * (1.0f / det);
-        ok = !(det < 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109
+        ok = PT_LANES(!(det < 1e-8f)) & PT_LANES(!(u < 0.0f)) & PT_LANES(!(u > 1.0f));  // :100, :109
     }
-    return ok ? 1u : 0u;
+    return ok;
 }
 
 // dynamic LDS of the trace kernels: the workgroup's copy of the hot triangle records
@@ -288,8 +338,8 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
 // sign passes them), so the second triangle's filter needs no cross product: 14 VALU instead of 20.
 // The host enables this only when EVERY pair (2k, 2k+1) of the scene satisfies e2' == -e2
 // (checked by pt_prep_kernel); returns the two mask bits (bit 0: triangle 2k, bit 1: 2k+1).
-PTK_DEV unsigned pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float bp1z, float be1x, float be1y, float be1z,
-                               const f3& o, const f3& d)
+PTK_DEV void pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float bp1z, float be1x, float be1y, float be1z,
+                           const f3& o, const f3& d, pt_lanes& okA, pt_lanes& okB)
 {
     float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y));
     float pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z));
@@ -297,42 +347,97 @@ PTK_DEV unsigned pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float 
     float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
     float tax = o.x - a.p1x, tay = o.y - a.p1y, taz = o.z - a.p1z;
     float unA = pt_fma(taz, pvz, pt_fma(tay, pvy, tax * pvx));
-    bool okA = !(unA < -1e-24f) & !(unA > detA * 1.000001f);
+    okA = PT_LANES(!(unA < -1e-24f)) & PT_LANES(!(unA > detA * 1.000001f));
     // second triangle: det' = -q, un' = -r;  !(un' < -1e-24) & !(un' > det' * 1.000001f)
     float q = pt_fma(be1z, pvz, pt_fma(be1y, pvy, be1x * pvx));
     float tbx = o.x - bp1x, tby = o.y - bp1y, tbz = o.z - bp1z;
     float r = pt_fma(tbz, pvz, pt_fma(tby, pvy, tbx * pvx));
-    bool okB = !(r > 1e-24f) & !(r < q * 1.000001f);
-    return (okA ? 1u : 0u) | (okB ? 2u : 0u);
+    okB = PT_LANES(!(r > 1e-24f)) & PT_LANES(!(r < q * 1.000001f));
 }
 
-template <bool DET_BOUNDED, bool LDS_TABLE, bool QUADS>
+// Pass 1 for a quad (a,b,c),(c,d,a) in MODE 2: ONE u numerator decides both triangles.
+//
+// In A's barycentric frame the second triangle B is the strip u in [-1, 0]: with p1' = c,
+// e2' = -e2 (so pvec' = -pvec bit for bit) the reference's own quantities for B are
+//     un'  = -fl_dot(fl(o - c), pvec)        det' = -fl_dot(e1', pvec)
+// and, were the arithmetic exact and the pair a parallelogram (e1' = -e1), un' = -unA and
+// det' = detA.  In binary32 the two differ by rounding and by how far the pair is from a
+// parallelogram.  With u = 2^-24, w = e1' + e1, every |coordinate difference| <= D and
+// |dir|_2^2 <= 1.001 (both CHECKED per ray by the caller: a ray that violates them keeps every
+// triangle), writing pvec = dir x e2 + zeta:
+//   |un' + unA| <= |e2.zeta| + |(sigma + rho).pvec| + |eta_a| + |eta_b|
+//               <= (9.3 + 6 + 12 + 36) u D^2 < 64 u D^2,          delta1 := 128 u D^2
+//       (zeta: rounding of the cross product, <= 3.1 u D per component; sigma = (c - a) - fl(c - a);
+//        rho: rounding of o - a and o - c; eta: rounding of a 3-term fma dot, <= 3 u sum|x_i p_i|)
+//   |det' - detA| <= |w.pvec| + |eta| + |eta'| <= |w|_2 |e2|_2 1.001 + (18.6 + 36) u D^2 =: delta2
+// A pair the reference accepts for B has det' >= 1e-8 and 0 <= u' <= 1, hence (pt_tri_pass1)
+// -1e-24 <= un' <= det' * 1.000001, hence
+//     unA <= delta1 + 1e-24      and      unA >= -(detA * 1.000001 + delta2 * 1.000001 + delta1).
+// The filter below keeps a superset of that (m = fl(detA * 1.000002f) >= detA * 1.000001 for
+// detA >= 0; for detA < 0 acceptance needs |detA| <= delta2, where the 0.1 % inflation of delta3
+// dominates the 1e-6 relative difference).  delta3 = delta2 * c + delta1 comes prepared per pair
+// (pt_prep_quad_margins_kernel).  A NaN anywhere fails every comparison and is kept.
+// 25 VALU per quad instead of 34.  tools/validate_filter.py re-checks every dropped pair against
+// the literal reference predicate (profiles/r01/filter_validation.txt).
+PTK_DEV void pt_quad2_pass1(const PtTriRec& a, float delta3, float delta1, const f3& o, const f3& d, pt_lanes& okA, pt_lanes& okB)
+{
+    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y));
+    float pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z));
+    float pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
+    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
+    float tax = o.x - a.p1x, tay = o.y - a.p1y, taz = o.z - a.p1z;
+    float unA = pt_fma(taz, pvz, pt_fma(tay, pvy, tax * pvx));
+    float m = detA * 1.000002f;
+    okA = PT_LANES(!(unA < -1e-24f)) & PT_LANES(!(unA > m));
+    okB = PT_LANES(!(unA > delta1)) & PT_LANES(!(unA < -(m + delta3)));
+}
+
+// QUADS: 0 = independent triangles, 1 = pt_quad_pass1, 2 = pt_quad2_pass1
+template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx,
-                                       unsigned long long* vstat = nullptr)
+                                       float delta1, float ray_radius, unsigned long long* vstat = nullptr)
 {
-    (void)vstat;
+    (void)vstat; (void)delta1; (void)ray_radius;
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
+    // mode 2: the assumptions of pt_quad2_pass1's error bound, checked for THIS ray
+    bool tame = true;
+    if (QUADS == 2 && DET_BOUNDED) {
+        float dd = pt_fma(d.z, d.z, pt_fma(d.y, d.y, d.x * d.x));
+        tame = (dd <= 1.001f) & (__builtin_fabsf(o.x - PT_EYE_X) <= ray_radius) &
+               (__builtin_fabsf(o.y - PT_EYE_Y) <= ray_radius) & (__builtin_fabsf(o.z - PT_EYE_Z) <= ray_radius);
+    }
     for (int base = 0; base < ntri; base += 32) {
         const int n = ntri - base < 32 ? ntri - base : 32;
-        unsigned m = 0u;  // bit j <-> triangle base + j
-        if (QUADS && DET_BOUNDED) {
+        unsigned m = 0u;  // bit n-1-j <-> triangle base + j (pt_push_flag)
+        if (QUADS == 2 && DET_BOUNDED) {
+            for (int j = 0; j < n; j += 2) {
+                const PtTriRec a = pt_load_tri(T, base + j);
+                const float delta3 = T[16 * (base + j + 1) + 9];  // pad0[0] of the pair's second record
+                pt_lanes okA, okB;
+                pt_quad2_pass1(a, delta3, delta1, o, d, okA, okB);
+                m = pt_push_flag(pt_push_flag(m, okA), okB);
+            }
+            if (!tame) m = n == 32 ? ~0u : (1u << n) - 1u;
+        } else if (QUADS == 1 && DET_BOUNDED) {
             // ntri is even and every (2k, 2k+1) is a quad; base and n are even
             for (int j = 0; j < n; j += 2) {
                 const PtTriRec a = pt_load_tri(T, base + j);
                 pt_const_f32p tb = T + 16 * (base + j + 1);
-                m |= pt_quad_pass1(a, tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], o, d) << j;
+                pt_lanes okA, okB;
+                pt_quad_pass1(a, tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], o, d, okA, okB);
+                m = pt_push_flag(pt_push_flag(m, okA), okB);
             }
         } else {
             PtTriRec a = pt_load_tri(T, base);
             int j = 0;
             for (; j + 1 < n; j += 2) {
                 PtTriRec b = pt_load_tri(T, base + j + 1);
-                m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
+                m = pt_push_flag(m, pt_tri_pass1<DET_BOUNDED>(a, o, d));
                 a = pt_load_tri(T, base + (j + 2 < n ? j + 2 : j + 1));
-                m |= pt_tri_pass1<DET_BOUNDED>(b, o, d) << (j + 1);
+                m = pt_push_flag(m, pt_tri_pass1<DET_BOUNDED>(b, o, d));
             }
-            if (j < n) m |= pt_tri_pass1<DET_BOUNDED>(a, o, d) << j;
+            if (j < n) m = pt_push_flag(m, pt_tri_pass1<DET_BOUNDED>(a, o, d));
         }
 #if PT_VALIDATE_FILTER
         // DIAGNOSTIC build (tools/validate_filter.py): the reference predicate of :100 and :109,
@@ -350,12 +455,33 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
                 float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
                 float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
                 keep = keep && !(u < 0.0f || u > 1.0f);
-                mx |= (keep ? 1u : 0u) << jj;
+                mx |= (keep ? 1u : 0u) << (n - 1 - jj);
             }
             atomicAdd(&vstat[0], (unsigned long long)n);                 // pairs examined
             atomicAdd(&vstat[1], (unsigned long long)__popc(mx));        // pairs the reference keeps
             atomicAdd(&vstat[2], (unsigned long long)__popc(m));         // pairs the filter keeps
             atomicAdd(&vstat[3], (unsigned long long)__popc(mx & ~m));   // VIOLATIONS: must stay 0
+            if (QUADS == 2 && DET_BOUNDED && tame) {
+                // headroom of pt_quad2_pass1's error bounds: the largest observed
+                // |un' + unA| / delta1 and (|det' - detA| c + |un' + unA|) / delta3 (both must be <= 1)
+                float r1 = 0.0f, r3 = 0.0f;
+                for (int jj = 0; jj + 1 < n; jj += 2) {
+                    const PtTriRec a = pt_load_tri(T, base + jj), b = pt_load_tri(T, base + jj + 1);
+                    const float delta3 = T[16 * (base + jj + 1) + 9];
+                    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y)), pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z)), pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
+                    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
+                    float unA = pt_fma(o.z - a.p1z, pvz, pt_fma(o.y - a.p1y, pvy, (o.x - a.p1x) * pvx));
+                    float qvx = pt_fma(d.y, b.e2z, -(d.z * b.e2y)), qvy = pt_fma(d.z, b.e2x, -(d.x * b.e2z)), qvz = pt_fma(d.x, b.e2y, -(d.y * b.e2x));
+                    float detB = pt_fma(b.e1z, qvz, pt_fma(b.e1y, qvy, b.e1x * qvx));
+                    float unB = pt_fma(o.z - b.p1z, qvz, pt_fma(o.y - b.p1y, qvy, (o.x - b.p1x) * qvx));
+                    float e1 = __builtin_fabsf(unB + unA), e2 = __builtin_fabsf(detB - detA);
+                    float q1 = e1 / delta1, q3 = (e2 * 1.000001f + e1) / delta3;
+                    r1 = q1 > r1 ? q1 : r1;
+                    r3 = q3 > r3 ? q3 : r3;
+                }
+                atomicMax(&vstat[4], (unsigned long long)__float_as_uint(r1));
+                atomicMax(&vstat[5], (unsigned long long)__float_as_uint(r3));
+            }
         }
 #endif
         if (!alive) m = 0u;  // a dead lane's stale ray must not cost pass-2 iterations
@@ -363,8 +489,10 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         while (__ballot(m != 0u) != 0ull) {
             ++steps;
             const bool valid = m != 0u;
-            const int i = base + (valid ? __builtin_ctz(m) : 0);
-            m &= m - 1u;
+            unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
+            asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
+            const int i = valid ? base + n - 32 + (int)lz : base;
+            m &= ~(0x80000000u >> (lz & 31u));
             const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
             pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
         }
@@ -594,7 +722,7 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 // LDS_TABLE: the workgroup keeps a copy of the prepared triangle records (stride 12 dwords:
 // conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
 // 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
-template <bool DET_BOUNDED, bool LDS_TABLE, bool QUADS>
+template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 // 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
 // (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
 // makes hipcc keep 94 SGPRs (2 spilled to VGPR lanes): 60.9 -> 59.8 ms.
@@ -637,6 +765,7 @@ void pt_trace_kernel(const PtTraceParams P)
         int hidx = -1;
 #if PT_TWO_PASS
         const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
+                                                                                          P.quad_delta1, P.ray_radius,
                                                                                           PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr);
 #if PT_STAMPS
         c_steps += p2steps;
@@ -943,28 +1072,38 @@ __global__ void pt_fill_i32_kernel(int32_t* dst, int32_t value, int n)
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(det_bound_bits, 0, 2 * sizeof(unsigned int), s);
+    hipError_t e = hipMemsetAsync(det_bound_bits, 0, PT_PREP_WORDS * sizeof(unsigned int), s);
     if (e != hipSuccess || ntri <= 0) return e;
     hipLaunchKernelGGL(pt_prep_kernel, dim3((ntri + 255) / 256), dim3(256), 0, s, raw, out, ntri, det_bound_bits);
     return hipGetLastError();
 }
 
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, bool quads, bool sorted, hipStream_t s)
+hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, hipStream_t s)
+{
+    if (ntri < 2) return hipSuccess;
+    const int pairs = ntri / 2;
+    hipLaunchKernelGGL(pt_prep_quad_margins_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, out, ntri, diameter, delta1);
+    return hipGetLastError();
+}
+
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, hipStream_t s)
 {
     if (sorted) {
         if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
     } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
         const size_t lds = (size_t)p.ntri * PT_LDS_TRI_STRIDE * sizeof(float);
-        if (det_bounded && quads && PT_QUAD_PAIRS)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (det_bounded && quads == 2 && PT_QUAD_PAIRS)
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, 2>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else if (det_bounded && quads == 1 && PT_QUAD_PAIRS)
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, 1>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else if (det_bounded)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else
-            hipLaunchKernelGGL((pt_trace_kernel<false, true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            hipLaunchKernelGGL((pt_trace_kernel<false, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
     }
     return hipGetLastError();
 }

@@ -83,7 +83,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -92,8 +92,10 @@ struct pt_device_s {
     uint64_t prep_version;
     int prep_ntri;
     bool prep_det_bounded;      // scene extent allows the short exact reciprocal
-    bool prep_quads;            // every triangle pair (2k, 2k+1) is a quad with e2' == -e2
-    unsigned int* det_bound_dev;  // two device words written by the prep kernel
+    int prep_quads;             // 0: no pair structure; 1: every pair (2k, 2k+1) has e2' == -e2;
+                                // 2: additionally p1' == p3, finite radius, margins prepared
+    float prep_delta1, prep_ray_radius;  // quad mode 2 (pt_quad2_pass1)
+    unsigned int* det_bound_dev;  // PT_PREP_WORDS device words written by the prep kernel
     // fused-render workspace
     float4* rad;
     size_t rad_bytes;
@@ -196,11 +198,12 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_chunk = 0;
     d->opt_profile = 0;
     d->opt_variant = 0;
+    d->opt_quads = 0;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
-        hipMalloc(&d->det_bound_dev, 2 * sizeof(unsigned int)) != hipSuccess) {
+        hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
@@ -314,6 +317,10 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
         if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "trace variant must be 0 (auto), 1 or 2");
         d->opt_variant = value;
         return PT_OK;
+    case PT_OPT_QUAD_FILTER:
+        if (value < 0 || value > 3) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1 (off), 2 (pairs) or 3 (shared u)");
+        d->opt_quads = value;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -326,6 +333,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_CHUNK_FRAMES: return d->opt_chunk;
     case PT_OPT_PROFILE_RETURN_TIME: return d->opt_profile;
     case PT_OPT_TRACE_VARIANT: return d->opt_variant;
+    case PT_OPT_QUAD_FILTER: return d->opt_quads;
     default: return -1;
     }
 }
@@ -611,13 +619,28 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     // wrapped (caller-owned) memory can change behind our back: always re-prepare it
     if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned) return PT_OK;
     HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->det_bound_dev, d->stream));
-    unsigned int words[2] = { 0u, 1u };
+    unsigned int words[PT_PREP_WORDS] = { 0u, 1u, 0x7fc00000u, 1u };
     HIP_TRY(hipMemcpyAsync(words, d->det_bound_dev, sizeof words, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));  // once per scene upload
-    float bound;
+    float bound, radius;
     memcpy(&bound, &words[0], sizeof bound);
+    memcpy(&radius, &words[2], sizeof radius);
     d->prep_det_bounded = bound <= PT_DET_BOUND_MAX;  // false for NaN / Inf too
-    d->prep_quads = words[1] == 0u && ntri > 0 && (ntri & 1) == 0;
+    d->prep_quads = (words[1] == 0u && ntri > 0 && (ntri & 1) == 0) ? 1 : 0;
+    d->prep_delta1 = 0.0f;
+    d->prep_ray_radius = 0.0f;
+    if (d->prep_quads == 1 && d->prep_det_bounded && words[3] == 0u && radius <= 1.0e15f) {
+        // quad mode 2: secondary rays start 0.01 off a surface (GenerateColors.cl:253), so their
+        // origins stay within ray_radius of the eye; D bounds every coordinate difference between
+        // two points of that box; delta1 = 128 u D^2 (derivation: pt_quad2_pass1)
+        const float ray_radius = radius * 1.001f + 0.05f;
+        const float diameter = 2.0f * ray_radius * 1.001f;
+        const float delta1 = 128.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
+        HIP_TRY(ptk_prep_quad_margins(d->prep, ntri, diameter, delta1, d->stream));
+        d->prep_quads = 2;
+        d->prep_delta1 = delta1;
+        d->prep_ray_radius = ray_radius;
+    }
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
@@ -718,6 +741,10 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.npix_local = npix;
         tp.batches_per_frame = bpf;
         tp.total_batches = (uint32_t)total_batches;
+        tp.quad_delta1 = d->prep_delta1;
+        tp.ray_radius = d->prep_ray_radius;
+        // PT_OPT_QUAD_FILTER: 0 = best the scene allows, k = at most mode k-1
+        const int quads = d->opt_quads ? std::min(d->prep_quads, (int)d->opt_quads - 1) : d->prep_quads;
         // persistent grid: fill the chip, but never more waves than batches
         const bool sorted = d->opt_variant == 2 || (d->opt_variant == 0 && PT_DEFAULT_SORTED);
         const int wg_waves = (sorted ? PT_SORT_THREADS : PT_TRACE_THREADS) / 64;
@@ -727,7 +754,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, d->prep_quads, sorted, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, sorted, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;

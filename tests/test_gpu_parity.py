@@ -269,16 +269,37 @@ def _variant_scene(kind):
     elif kind == "degenerate":      # zero-area and NaN triangles among the real ones
         tris[4]["p2"] = tris[4]["p1"]
         tris[7]["p3"][:3] = np.nan
+    elif kind == "quads_skewed":    # (a,b,c),(c,d,a) pairs far from parallelograms: shared-u filter, wide margins
+        rng = np.random.default_rng(7)
+        tris["p2"][1::2, :3] += rng.uniform(-0.4, 0.4, (len(tris) // 2, 3)).astype(np.float32)
+    elif kind == "quads_tiny":      # the box shrunk to 5 cm in front of the eye: shared-u margins at their floor
+        eye = np.array([0.0, 2.75, 4.0], np.float32)
+        for f in ("p1", "p2", "p3"):
+            tris[f][:, :3] = (tris[f][:, :3] - eye) * np.float32(0.01) + eye + np.array([0.0, 0.0, -0.05], np.float32)
+    elif kind == "quads_detached":  # second triangles translated: e2' == -e2 still, p1' != p3: pair filter only
+        for f in ("p1", "p2", "p3"):
+            tris[f][1::2, :3] += np.array([0.25, -0.125, 0.5], np.float32)
+    elif kind == "quads_nan_second":  # a NaN in the second triangle's e1 only: the pair structure survives
+        tris["p2"][9, 1] = np.nan
+    elif kind == "quads_far":       # scene far from the eye relative to its size: large radius, small triangles
+        for f in ("p1", "p2", "p3"):
+            tris[f][:, :3] = tris[f][:, :3] * np.float32(4.0) + np.array([0.0, -8.25, -160.0], np.float32)
     return tris, mats
 
 
-@pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate"])
-def test_kernel_specialisations_match_oracle(device, oracle, kind):
+@pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate",
+                                  "quads_skewed", "quads_tiny", "quads_detached", "quads_nan_second", "quads_far"])
+@pytest.mark.parametrize("quad_filter", [0, 1, 2])
+def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
+    """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows, 1 = none, 2 = pairs."""
+    from oclpathtracer_amd import shim
+
     tris, mats = _variant_scene(kind)
     W, H, frames = 64, 48, 3
     want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
     from oclpathtracer_amd.render import Renderer
 
+    device.setOption(shim.PT_OPT_QUAD_FILTER, quad_filter)
     r = Renderer(device, tris, mats, W, H, want_stats=True)
     try:
         r.render(frames)
@@ -286,5 +307,6 @@ def test_kernel_specialisations_match_oracle(device, oracle, kind):
         gst = r.read_stats()
     finally:
         r.release()
+        device.setOption(shim.PT_OPT_QUAD_FILTER, 0)
     assert_fb_equal(got, want, kind)
     assert gst["rays"] == st["rays"]
