@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="trace kernel: 0 library default, 1 lane-regenerating, 2 octant-sorted")
+    ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 2 pairs, 3 shared u, 4 packed")
     args = ap.parse_args()
 
     import torch  # first: the shim must bind to the HIP runtime torch already loaded
@@ -145,6 +146,7 @@ def main():
     dev = adl.DeviceUtils.allocate(adl.TYPE_HIP, adl.Config(local_rank))
     lib = shim.load()
     dev.setOption(shim.PT_OPT_TRACE_VARIANT, args.variant)
+    dev.setOption(shim.PT_OPT_QUAD_FILTER, args.quad_filter)
     img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True)
 
     def step():

@@ -108,7 +108,8 @@ enum pt_option {
     /* conservative pass-1 filter of the closest-hit search, for A/B timing and parity tests:
      * 0 = the strongest the uploaded scene allows, 1 = independent triangles, 2 = at most the
      * pair filter (shared cross product), 3 = at most the shared-u filter (one numerator decides
-     * both triangles of an (a,b,c),(c,d,a) pair).  All settings produce identical pixels. */
+     * both triangles of an (a,b,c),(c,d,a) pair), 4 = at most its packed Pluecker form (two quads
+     * per instruction).  All settings produce identical pixels. */
     PT_OPT_QUAD_FILTER = 4
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);

@@ -46,7 +46,9 @@ struct PtTraceParams {
     uint32_t npix_local;
     uint32_t batches_per_frame, total_batches;
     float quad_delta1;            // quad mode 2 (pt_quad2_pass1): slack of the shared-u bounds
-    float ray_radius;             // quad mode 2: rays with |origin - eye|_inf above this keep every triangle
+    float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
+    const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
+    float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
 };
 
 struct PtFoldParams {
@@ -65,10 +67,14 @@ hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int
                               hipStream_t s);
 // quad mode 2: writes every odd record's pad0[0] = slack of its shared-u bound (needs the scene
 // diameter bound D from word [2] of the first pass, hence a second tiny launch)
-hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, hipStream_t s);
+// p1tab (may be null): quad mode 3's table, PT_P1_STRIDE floats per pair of quads (pt_quad3_pass1)
+hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, float* p1tab, hipStream_t s);
+#define PT_P1_STRIDE 24  // floats per quad pair: nx ny nz e2x e2y e2z Kx Ky Kz dhi, each {quad 2p, quad 2p+1}, 4 pad
+static inline size_t ptk_p1tab_floats(int ntri) { return (size_t)((ntri / 2 + 1) / 2) * PT_P1_STRIDE; }
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
 // quads: 0 = none; 1 = ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1);
 //        2 = additionally p1' == p3 and the margins are prepared (pt_quad2_pass1)
+//        3 = as 2, evaluated from the packed table p.p1tab (pt_quad3_pass1)
 hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #ifndef PT_DEFAULT_SORTED

@@ -98,6 +98,38 @@ __global__ void pt_prep_quad_margins_kernel(PtPrepTriangle* __restrict__ out, in
     out[i].pad0[0] = delta3;  // +Inf / NaN keep every second triangle of the pair: valid, merely slow
 }
 
+// Third pass of the scene preparation, quad mode 3 (pt_quad3_pass1): per PAIR of quads (2p, 2p+1)
+// the operands of the packed pass-1 filter, interleaved {quad 2p, quad 2p+1} so that every one is
+// an SGPR pair of a v_pk_fma_f32:
+//   n' = cross(e2, e1) * 1.000002f   (det * c = dir . n')
+//   e2, K = cross(e2, a - eye)       (un = e2 . ((o - eye) x dir) - dir . K)
+//   dhi = delta3 + deltaD * c + deltaP (slack of the outer bound; -1 for the padding quad)
+__global__ void pt_prep_p1tab_kernel(const PtPrepTriangle* __restrict__ tris, int ntri, float diameter, float* __restrict__ tab)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nquads = ntri / 2;
+    if (2 * p >= nquads) return;
+    const float uD2 = 5.9604645e-8f * diameter * diameter;
+    const float deltaP = 192.0f * uD2 * 1.001f, deltaD = 128.0f * uD2 * 1.001f;
+    float* t = tab + (size_t)p * PT_P1_STRIDE;
+    for (int h = 0; h < 2; ++h) {
+        const int q = 2 * p + h;
+        float v[10] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, -1.0f };  // padding: |un| = 0 > -1 fails
+        if (q < nquads) {
+            const PtPrepTriangle a = tris[2 * q], b = tris[2 * q + 1];
+            const f3 e2 = mk3(a.e2[0], a.e2[1], a.e2[2]);
+            const f3 ac = mk3(a.p1[0] - PT_EYE_X, a.p1[1] - PT_EYE_Y, a.p1[2] - PT_EYE_Z);
+            const f3 K = cross3(e2, ac);
+            v[0] = a.n[0] * 1.000002f; v[1] = a.n[1] * 1.000002f; v[2] = a.n[2] * 1.000002f;
+            v[3] = e2.x; v[4] = e2.y; v[5] = e2.z;
+            v[6] = K.x; v[7] = K.y; v[8] = K.z;
+            v[9] = (b.pad0[0] + deltaD * 1.000002f + deltaP) * 1.001f;
+        }
+        for (int k = 0; k < 10; ++k) t[2 * k + h] = v[k];
+    }
+    for (int k = 20; k < PT_P1_STRIDE; ++k) t[k] = 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------
 // camera: GenerateColors.cl:73-87, 263-288
 // ------------------------------------------------------------------------------------------
@@ -392,17 +424,87 @@ PTK_DEV void pt_quad2_pass1(const PtTriRec& a, float delta3, float delta1, const
     okB = PT_LANES(!(unA > delta1)) & PT_LANES(!(unA < -(m + delta3)));
 }
 
-// QUADS: 0 = independent triangles, 1 = pt_quad_pass1, 2 = pt_quad2_pass1
+// Pass 1 in MODE 3: the shared-u filter of mode 2 evaluated in Pluecker form, two quads per
+// instruction.  tools/ubench_issue (profiles/r01/ubench_issue.log): on gfx950 an fp32 FMA/MUL/ADD
+// whose operands are all VGPRs issues at double rate (~2.7 cycles per wave), ANY SGPR operand
+// makes it single rate (~4.5), and v_pk_fma_f32 costs ~4.9 with or without an SGPR pair.  Mode 2
+// spends 16 single-rate instructions per quad on SGPR operands; here
+//     un  = tvec . (dir x e2) = e2 . ((o - eye) x dir) - dir . K,     K  = e2 x (a - eye)
+//     T   = det * c + dhi     = dir . n' + dhi,                       n' = (e2 x e1) * c
+// with M = (o - eye) x dir computed once per ray: 9 v_pk_fma_f32 give un and T of TWO quads, whose
+// per-quad constants come interleaved from the table pt_prep_p1tab_kernel wrote.
+// These are other roundings of the same real numbers than the reference's, so BOTH triangles now
+// need slack (same assumptions as mode 2: D bounds every coordinate difference, |dir|^2 <= 1.001,
+// u = 2^-24):
+//   |un_here - un_ref|   <= 33.3 u D^2 (reference: tvec, cross, 3-term dot)
+//                         + 51 u D^2 (here: o - eye, M, a - eye, K, 6-term fma chain)   < 192 u D^2 =: deltaP
+//   |det_here - det_ref| <= 27.3 u D^2 + 27 u D^2 + 12 u D^2 (c folded into n', dhi into the chain) < 128 u D^2 =: deltaD
+// A pair the reference accepts satisfies (pt_tri_pass1, pt_quad2_pass1)
+//   first triangle:  -1e-24 <= un_ref <= det_ref c            second: -(det_ref c + delta3) <= un_ref <= delta1
+// hence, with dhi = delta3 + deltaD c + deltaP >= deltaD c + deltaP,
+//   both: |un_here| <= T;     first: un_here >= -deltaP (= lo);     second: un_here <= delta1 + deltaP (= hi).
+// 9 packed + 6 compares + 4 v_addc per PAIR of quads (mode 2: 46).  NaNs fail every comparison and are kept.
+typedef float pt_f2 __attribute__((ext_vector_type(2)));
+// r = a.lo * s / a.hi * s / fma with the VGPR half broadcast to both results; s = SGPR pair
+PTK_DEV pt_f2 pt_pk_mul_lo(pt_f2 a, pt_f2 s) { pt_f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(s)); return r; }
+PTK_DEV pt_f2 pt_pk_mul_hi(pt_f2 a, pt_f2 s) { pt_f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "s"(s)); return r; }
+PTK_DEV pt_f2 pt_pk_fma_lo(pt_f2 a, pt_f2 s, pt_f2 c) { pt_f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
+PTK_DEV pt_f2 pt_pk_fma_hi(pt_f2 a, pt_f2 s, pt_f2 c) { pt_f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
+PTK_DEV pt_f2 pt_pk_fnma_lo(pt_f2 a, pt_f2 s, pt_f2 c) { pt_f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
+PTK_DEV pt_f2 pt_pk_fnma_hi(pt_f2 a, pt_f2 s, pt_f2 c) { pt_f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(s), "v"(c)); return r; }
+// dhi + a.lo * s: the addend is the SGPR pair, the product's second factor too (one constant-bus
+// operand only): so dhi is first copied to VGPRs by the first product instead -- see pt_quad3_pass1
+struct PtRay3 { pt_f2 dxy, dzMx, Myz; };  // dir and M = (o - eye) x dir, as three register pairs
+
+PTK_DEV void pt_quad3_pass1(pt_const_f32p t, const PtRay3& r, pt_f2& un, pt_f2& T)
+{
+    typedef const __attribute__((address_space(4))) pt_f2* pt_const_f2p;
+    pt_const_f2p s = (pt_const_f2p)t;  // nx ny nz e2x e2y e2z Kx Ky Kz dhi
+    pt_f2 dhi_v;
+    { const pt_f2 dhi = s[9]; asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=v"(dhi_v) : "s"(dhi)); }
+    T = pt_pk_fma_lo(r.dxy, s[0], dhi_v);
+    T = pt_pk_fma_hi(r.dxy, s[1], T);
+    T = pt_pk_fma_lo(r.dzMx, s[2], T);
+    un = pt_pk_mul_hi(r.dzMx, s[3]);
+    un = pt_pk_fma_lo(r.Myz, s[4], un);
+    un = pt_pk_fma_hi(r.Myz, s[5], un);
+    un = pt_pk_fnma_lo(r.dxy, s[6], un);
+    un = pt_pk_fnma_hi(r.dxy, s[7], un);
+    un = pt_pk_fnma_lo(r.dzMx, s[8], un);
+}
+
+// PT_STAMPS=1 is a DIAGNOSTIC build (tools/stamps.py): per-phase s_memtime shares of a
+// wave-bounce go to stats[2..5]; never shipped, never timed for the bench.
+#ifndef PT_STAMPS
+#define PT_STAMPS 0
+#endif
+#if PT_STAMPS
+#define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_STAMP(var) do { } while (0)
+#endif
+
+// QUADS: 0 = independent triangles, 1 = pt_quad_pass1, 2 = pt_quad2_pass1, 3 = pt_quad3_pass1
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx,
-                                       float delta1, float ray_radius, unsigned long long* vstat = nullptr)
+                                       float delta1, float ray_radius, pt_const_f32p p1tab, float p1_lo, float p1_hi,
+                                       unsigned long long* vstat = nullptr, unsigned long long* p1_ticks = nullptr)
 {
-    (void)vstat; (void)delta1; (void)ray_radius;
+#if PT_STAMPS
+    unsigned long long ta = 0, tb = 0;
+#endif
+    (void)vstat; (void)p1_ticks; (void)delta1; (void)ray_radius; (void)p1tab; (void)p1_lo; (void)p1_hi;
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
     // mode 2: the assumptions of pt_quad2_pass1's error bound, checked for THIS ray
     bool tame = true;
-    if (QUADS == 2 && DET_BOUNDED) {
+    PtRay3 r3;
+    if (QUADS == 3 && DET_BOUNDED) {
+        const f3 oc = mk3(o.x - PT_EYE_X, o.y - PT_EYE_Y, o.z - PT_EYE_Z);
+        const f3 M = cross3(oc, d);
+        r3.dxy = pt_f2{ d.x, d.y }; r3.dzMx = pt_f2{ d.z, M.x }; r3.Myz = pt_f2{ M.y, M.z };
+    }
+    if (QUADS >= 2 && DET_BOUNDED) {
         float dd = pt_fma(d.z, d.z, pt_fma(d.y, d.y, d.x * d.x));
         tame = (dd <= 1.001f) & (__builtin_fabsf(o.x - PT_EYE_X) <= ray_radius) &
                (__builtin_fabsf(o.y - PT_EYE_Y) <= ray_radius) & (__builtin_fabsf(o.z - PT_EYE_Z) <= ray_radius);
@@ -410,7 +512,23 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
     for (int base = 0; base < ntri; base += 32) {
         const int n = ntri - base < 32 ? ntri - base : 32;
         unsigned m = 0u;  // bit n-1-j <-> triangle base + j (pt_push_flag)
-        if (QUADS == 2 && DET_BOUNDED) {
+        PT_STAMP(ta);
+        if (QUADS == 3 && DET_BOUNDED) {
+            pt_const_f32p tp = p1tab + PT_P1_STRIDE * (base >> 2);  // base is a multiple of 32: 4 triangles per quad pair
+            for (int j = 0; j < n; j += 4, tp += PT_P1_STRIDE) {
+                pt_f2 un, th;
+                pt_quad3_pass1(tp, r3, un, th);
+                {
+                    const pt_lanes in = PT_LANES(!(__builtin_fabsf(un.x) > th.x));
+                    m = pt_push_flag(pt_push_flag(m, in & PT_LANES(!(un.x < p1_lo))), in & PT_LANES(!(un.x > p1_hi)));
+                }
+                if (j + 2 < n) {
+                    const pt_lanes in = PT_LANES(!(__builtin_fabsf(un.y) > th.y));
+                    m = pt_push_flag(pt_push_flag(m, in & PT_LANES(!(un.y < p1_lo))), in & PT_LANES(!(un.y > p1_hi)));
+                }
+            }
+            if (!tame) m = n == 32 ? ~0u : (1u << n) - 1u;
+        } else if (QUADS == 2 && DET_BOUNDED) {
             for (int j = 0; j < n; j += 2) {
                 const PtTriRec a = pt_load_tri(T, base + j);
                 const float delta3 = T[16 * (base + j + 1) + 9];  // pad0[0] of the pair's second record
@@ -461,7 +579,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             atomicAdd(&vstat[1], (unsigned long long)__popc(mx));        // pairs the reference keeps
             atomicAdd(&vstat[2], (unsigned long long)__popc(m));         // pairs the filter keeps
             atomicAdd(&vstat[3], (unsigned long long)__popc(mx & ~m));   // VIOLATIONS: must stay 0
-            if (QUADS == 2 && DET_BOUNDED && tame) {
+            if (QUADS >= 2 && DET_BOUNDED && tame) {
                 // headroom of pt_quad2_pass1's error bounds: the largest observed
                 // |un' + unA| / delta1 and (|det' - detA| c + |un' + unA|) / delta3 (both must be <= 1)
                 float r1 = 0.0f, r3 = 0.0f;
@@ -485,6 +603,10 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         }
 #endif
         if (!alive) m = 0u;  // a dead lane's stale ray must not cost pass-2 iterations
+#if PT_STAMPS
+        PT_STAMP(tb);
+        if (p1_ticks) *p1_ticks += tb - ta;
+#endif
         // every lane tests its next survivor (index 0 and ok = false once it has none left)
         while (__ballot(m != 0u) != 0ull) {
             ++steps;
@@ -503,16 +625,6 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
 // ------------------------------------------------------------------------------------------
 // trace kernels
 // ------------------------------------------------------------------------------------------
-// PT_STAMPS=1 is a DIAGNOSTIC build (tools/stamps.py): per-phase s_memtime shares of a
-// wave-bounce go to stats[2..5]; never shipped, never timed for the bench.
-#ifndef PT_STAMPS
-#define PT_STAMPS 0
-#endif
-#if PT_STAMPS
-#define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PT_STAMP(var) do { } while (0)
-#endif
 
 // one path: 16 dwords (the unit the octant-sorted kernel moves between lanes)
 struct PtPath {
@@ -591,8 +703,16 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
 // HAVE_UV: the caller's closest-hit search carried (u,v); otherwise they are recomputed here
 template <bool DET_BOUNDED, bool HAVE_UV>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
-                      unsigned& n_rays, unsigned& n_samples)
+                      unsigned& n_rays, unsigned& n_samples, unsigned long long* sub = nullptr)
 {
+#if PT_STAMPS == 2
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
+#define PT_SUB(var) PT_STAMP(var)
+#else
+#define PT_SUB(var) do { } while (0)
+#endif
+    (void)sub;
+    PT_SUB(q0);
     bool finished = false;
     n_rays++;
     if (hidx < 0) {
@@ -609,6 +729,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         __builtin_amdgcn_sched_barrier(0);
         pt_sincos(phi, sp, cp);
         __builtin_amdgcn_sched_barrier(0);
+        PT_SUB(q1);
 
         // deferred HitRecord of the closest hit (:127-130): same values as writing it at every
         // acceptance, only the last one is read.
@@ -633,12 +754,14 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
 
         n = dot3(n, s.d) < 0.0f ? n : scale3(n, -1.0f);  // :243
         f3 wo = neg3(s.d);
+        PT_SUB(q2);
 
         // sampleHemisphereCosine (:161-172) and sampleGGX (:180-192) share everything
         // except (sinTheta, cosTheta)
         f3 axis = __builtin_fabsf(n.x) > 0.001f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
         f3 tv = normalize3(cross3(axis, n));
         f3 sv = cross3(n, tv);
+        PT_SUB(q3);
         // one sqrt pair for both BRDFs (a wave usually holds both material types): only the
         // radicands differ -- diffuse: sqrt(xi), sqrt(1-xi); GGX: sqrt((1-xi)/(xi(r^2-1)+1)), then
         // sqrt(max(0, 1-cos^2))
@@ -651,6 +774,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         f3 b = scale3(scale3(tv, sp), sinTheta);
         f3 c = scale3(n, cosTheta);
         f3 sdir = normalize3(add3(add3(a, b), c));
+        PT_SUB(q4);
 
         f3 wi = sdir;
         f3 color = mk3(0.0f, 0.0f, 0.0f);
@@ -674,6 +798,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
                 color = mk3(alb.x * g * 2.0f, alb.y * g * 2.0f, alb.z * g * 2.0f);
             }
         }
+        PT_SUB(q5);
         if (pdf <= 0.0f) {  // :251
             finished = true;
         } else {
@@ -699,6 +824,11 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         n_samples++;
         alive = false;
     }
+#if PT_STAMPS == 2
+    PT_SUB(q6);
+    if (sub && q1) { sub[0] += q1 - q0; sub[1] += q2 - q1; sub[2] += q3 - q2; sub[3] += q4 - q3; sub[4] += q5 - q4; sub[5] += q6 - q5; }
+#endif
+#undef PT_SUB
 }
 
 PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n_rays, unsigned n_samples)
@@ -749,7 +879,10 @@ void pt_trace_kernel(const PtTraceParams P)
     s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
     unsigned n_rays = 0, n_samples = 0;
 #if PT_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0, c_p1 = 0;
+#endif
+#if PT_STAMPS == 2
+    unsigned long long c_sub[6] = { 0, 0, 0, 0, 0, 0 };
 #endif
 
     for (;;) {
@@ -766,7 +899,14 @@ void pt_trace_kernel(const PtTraceParams P)
 #if PT_TWO_PASS
         const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
-                                                                                          PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr);
+                                                                                          (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi,
+                                                                                          PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr,
+#if PT_STAMPS
+                                                                                          &c_p1
+#else
+                                                                                          nullptr
+#endif
+                                                                                          );
 #if PT_STAMPS
         c_steps += p2steps;
 #else
@@ -787,7 +927,11 @@ void pt_trace_kernel(const PtTraceParams P)
 #endif
 
         PT_STAMP(t2);
+#if PT_STAMPS == 2
+        if (alive) pt_shade<DET_BOUNDED, (PT_TWO_PASS || PT_TRACK_UV)>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
+#else
         if (alive) pt_shade<DET_BOUNDED, (PT_TWO_PASS || PT_TRACK_UV)>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+#endif
 #if PT_STAMPS
         PT_STAMP(t3);
         c_regen += t1 - t0; c_loop += t2 - t1; c_shade += t3 - t2; c_iters++;
@@ -796,11 +940,18 @@ void pt_trace_kernel(const PtTraceParams P)
 
 #if PT_STAMPS
     if (P.stats && lane == 0) {
+#if PT_STAMPS != 2
         atomicAdd(&P.stats[2], c_regen);
         atomicAdd(&P.stats[3], c_loop);
         atomicAdd(&P.stats[4], c_shade);
         atomicAdd(&P.stats[5], c_iters);
+#endif
+#if PT_STAMPS == 2
+        for (int k = 0; k < 6; ++k) atomicAdd(&P.stats[2 + k], c_sub[k]);  // shade sub-phases instead
+#else
         atomicAdd(&P.stats[7], c_steps);
+        atomicAdd(&P.stats[6], c_p1);
+#endif
     }
 #endif
     pt_flush_counters(P, lane, n_rays, n_samples);
@@ -1078,11 +1229,15 @@ hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int
     return hipGetLastError();
 }
 
-hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, hipStream_t s)
+hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, float* p1tab, hipStream_t s)
 {
     if (ntri < 2) return hipSuccess;
     const int pairs = ntri / 2;
     hipLaunchKernelGGL(pt_prep_quad_margins_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, out, ntri, diameter, delta1);
+    if (p1tab) {
+        const int qpairs = (pairs + 1) / 2;
+        hipLaunchKernelGGL(pt_prep_p1tab_kernel, dim3((qpairs + 255) / 256), dim3(256), 0, s, out, ntri, diameter, p1tab);
+    }
     return hipGetLastError();
 }
 
@@ -1093,7 +1248,9 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
     } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
         const size_t lds = (size_t)p.ntri * PT_LDS_TRI_STRIDE * sizeof(float);
-        if (det_bounded && quads == 2 && PT_QUAD_PAIRS)
+        if (det_bounded && quads == 3 && PT_QUAD_PAIRS)
+            hipLaunchKernelGGL((pt_trace_kernel<true, true, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else if (det_bounded && quads == 2 && PT_QUAD_PAIRS)
             hipLaunchKernelGGL((pt_trace_kernel<true, true, 2>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else if (det_bounded && quads == 1 && PT_QUAD_PAIRS)
             hipLaunchKernelGGL((pt_trace_kernel<true, true, 1>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);

@@ -94,7 +94,9 @@ struct pt_device_s {
     bool prep_det_bounded;      // scene extent allows the short exact reciprocal
     int prep_quads;             // 0: no pair structure; 1: every pair (2k, 2k+1) has e2' == -e2;
                                 // 2: additionally p1' == p3, finite radius, margins prepared
-    float prep_delta1, prep_ray_radius;  // quad mode 2 (pt_quad2_pass1)
+    float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
+    float* p1tab;               // quad mode 3: packed pass-1 table (pt_quad3_pass1), sized with prep
+    float prep_p1_lo, prep_p1_hi;
     unsigned int* det_bound_dev;  // PT_PREP_WORDS device words written by the prep kernel
     // fused-render workspace
     float4* rad;
@@ -226,6 +228,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->live_buffers != 0)
         return fail(PT_ERR_INVALID, "%d buffer(s) of this device are still alive", d->live_buffers);
     if (d->prep) hipFree(d->prep);
+    if (d->p1tab) hipFree(d->p1tab);
     if (d->rad) hipFree(d->rad);
     if (d->counters) hipFree(d->counters);
     if (d->det_bound_dev) hipFree(d->det_bound_dev);
@@ -318,7 +321,7 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
         d->opt_variant = value;
         return PT_OK;
     case PT_OPT_QUAD_FILTER:
-        if (value < 0 || value > 3) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1 (off), 2 (pairs) or 3 (shared u)");
+        if (value < 0 || value > 4) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1 (off), 2 (pairs), 3 (shared u) or 4 (packed shared u)");
         d->opt_quads = value;
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
@@ -608,10 +611,13 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     if (d->prep_capacity < (size_t)ntri) {
         HIP_TRY(hipStreamSynchronize(d->stream));
         if (d->prep) hipFree(d->prep);
+        if (d->p1tab) hipFree(d->p1tab);
         d->prep = nullptr;
+        d->p1tab = nullptr;
         d->prep_capacity = 0;
         size_t cap = std::max<size_t>((size_t)ntri, 64);
         hipError_t e = hipMalloc(&d->prep, cap * sizeof(PtPrepTriangle));
+        if (e == hipSuccess) e = hipMalloc(&d->p1tab, ptk_p1tab_floats((int)cap) * sizeof(float));
         if (e != hipSuccess) return fail(PT_ERR_OOM, "scene workspace allocation failed: %s", hipGetErrorString(e));
         d->prep_capacity = cap;
         d->prep_src = nullptr;
@@ -636,10 +642,14 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         const float ray_radius = radius * 1.001f + 0.05f;
         const float diameter = 2.0f * ray_radius * 1.001f;
         const float delta1 = 128.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
-        HIP_TRY(ptk_prep_quad_margins(d->prep, ntri, diameter, delta1, d->stream));
-        d->prep_quads = 2;
+        HIP_TRY(ptk_prep_quad_margins(d->prep, ntri, diameter, delta1, d->p1tab, d->stream));
+        d->prep_quads = 3;
         d->prep_delta1 = delta1;
         d->prep_ray_radius = ray_radius;
+        // mode 3 (pt_quad3_pass1): deltaP = 192 u D^2; first triangle un >= -deltaP, second un <= delta1 + deltaP
+        const float deltaP = 192.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
+        d->prep_p1_lo = -deltaP;
+        d->prep_p1_hi = (delta1 + deltaP) * 1.001f;
     }
     d->prep_src = tris;
     d->prep_version = tris->version;
@@ -743,6 +753,9 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.total_batches = (uint32_t)total_batches;
         tp.quad_delta1 = d->prep_delta1;
         tp.ray_radius = d->prep_ray_radius;
+        tp.p1tab = d->p1tab;
+        tp.p1_lo = d->prep_p1_lo;
+        tp.p1_hi = d->prep_p1_hi;
         // PT_OPT_QUAD_FILTER: 0 = best the scene allows, k = at most mode k-1
         const int quads = d->opt_quads ? std::min(d->prep_quads, (int)d->opt_quads - 1) : d->prep_quads;
         // persistent grid: fill the chip, but never more waves than batches

@@ -289,9 +289,9 @@ def _variant_scene(kind):
 
 @pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate",
                                   "quads_skewed", "quads_tiny", "quads_detached", "quads_nan_second", "quads_far"])
-@pytest.mark.parametrize("quad_filter", [0, 1, 2])
+@pytest.mark.parametrize("quad_filter", [0, 1, 2, 3])
 def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
-    """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows, 1 = none, 2 = pairs."""
+    """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows, 1 = none, 2 = pairs, 3 = shared u."""
     from oclpathtracer_amd import shim
 
     tris, mats = _variant_scene(kind)
