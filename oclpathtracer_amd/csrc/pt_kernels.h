@@ -86,4 +86,7 @@ hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width
 hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStream_t s);
 hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s);
 hipError_t ptk_math(const float* in, float* out, int n, hipStream_t s);
-int ptk_trace_blocks_per_cu(bool sorted);
+// dynamic LDS of variant 1: the triangle table (scenes up to PT_LDS_TRI_MAX) + one camera-ray slot
+// per sample of every wave's current batch
+size_t ptk_trace_lds_bytes(int ntri);
+int ptk_trace_blocks_per_cu(bool sorted, int ntri);

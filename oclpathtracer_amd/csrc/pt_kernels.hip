@@ -852,6 +852,83 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 // LDS_TABLE: the workgroup keeps a copy of the prepared triangle records (stride 12 dwords:
 // conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
 // 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
+// ---- regeneration, variant 1: camera rays made in bulk ------------------------------------------
+// A wave retires ~10 of its 64 paths per bounce, so generating their successors' camera rays on the
+// spot (2 RNG draws, 3 normalisations: ~160 VALU) ran at 15 % lane utilisation and cost 11 % of the
+// kernel.  Instead, when a wave takes a batch of PT_TRACE_BATCH samples off the queue it generates
+// ALL their primary rays at once, 64 lanes wide, into its slice of LDS (direction + RNG state,
+// 16 B per sample); a dead lane then restarts with one ds_read_b128.  Which lane runs which
+// sample never affects a sample's result.
+struct PtQueueB {
+    unsigned pix, end, frame, base;  // base: first local pixel of the current batch
+    bool exhausted;
+};
+
+PTK_DEV void pt_camera_batch(const PtTraceParams& P, unsigned lane, const PtQueueB& q, float4* cam)
+{
+    for (unsigned k = 0; k < PT_TRACE_BATCH; k += 64) {
+        const unsigned lp = q.base + k + lane;
+        if (lp < q.end) {
+            const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+            unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
+            if (P.n_ranks > 1) {
+                unsigned sl = lr / (unsigned)P.stripe_rows;
+                unsigned within = lr - sl * (unsigned)P.stripe_rows;
+                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+            }
+            const unsigned gid = grow * (unsigned)P.width + x;
+            const int frame = P.frame_begin + (int)q.frame;
+            uint32_t seed = gid + pt_hash_u32((uint32_t)frame);                        // :308
+            f3 o, d;
+            pt_generate_ray((int)x, (int)grow, P.width, P.height, seed, o, d);         // :310
+            cam[k + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(seed));
+        }
+    }
+    // the wave's own LDS writes, read back by other lanes of the same wave: program order suffices
+    // for the hardware (one in-order LDS queue per wave); this keeps the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+PTK_DEV void pt_regenerate_bulk(const PtTraceParams& P, unsigned lane, PtQueueB& q, PtPath& s, bool& alive, float4* cam)
+{
+    unsigned long long need = __ballot(!alive);
+    while (need != 0ull && !q.exhausted) {
+        if (q.pix == q.end) {
+            unsigned b = 0;
+            if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= P.total_batches) { q.exhausted = true; break; }
+            unsigned f = b / P.batches_per_frame;
+            unsigned bi = b - f * P.batches_per_frame;
+            q.frame = f;
+            q.pix = q.base = bi * PT_TRACE_BATCH;
+            unsigned e = q.pix + PT_TRACE_BATCH;
+            q.end = e < P.npix_local ? e : P.npix_local;
+            pt_camera_batch(P, lane, q, cam);
+        }
+        unsigned n_need = (unsigned)__popcll(need);
+        unsigned avail = q.end - q.pix;
+        unsigned take = n_need < avail ? n_need : avail;
+        unsigned rank = pt_mbcnt(need);
+        if (!alive && rank < take) {
+            s.lp = q.pix + rank;
+            s.fl = q.frame;
+            const float4 c = cam[s.lp - q.base];
+            s.o = mk3(PT_EYE_X, PT_EYE_Y, PT_EYE_Z);
+            s.d = mk3(c.x, c.y, c.z);
+            s.seed = __float_as_uint(c.w);
+            s.mask = mk3(1.0f, 1.0f, 1.0f);
+            s.L = mk3(0.0f, 0.0f, 0.0f);
+            s.bounce = 0;
+            alive = true;
+        }
+        q.pix += take;
+        need = __ballot(!alive);
+    }
+}
+
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 // 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
 // (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
@@ -870,8 +947,10 @@ void pt_trace_kernel(const PtTraceParams P)
         }
         __syncthreads();
     }
+    // this wave's PT_TRACE_BATCH camera-ray slots, behind the triangle table (ptk_trace_lds_bytes)
+    float4* cam = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * PT_TRACE_BATCH;
 
-    PtQueue q = { 0u, 0u, 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
+    PtQueueB q = { 0u, 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
@@ -887,7 +966,7 @@ void pt_trace_kernel(const PtTraceParams P)
 
     for (;;) {
         PT_STAMP(t0);
-        pt_regenerate(P, lane, q, s, alive);
+        pt_regenerate_bulk(P, lane, q, s, alive, cam);
         if (__ballot(alive) == 0ull) break;
         PT_STAMP(t1);
 
@@ -1247,7 +1326,7 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
         if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
     } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
-        const size_t lds = (size_t)p.ntri * PT_LDS_TRI_STRIDE * sizeof(float);
+        const size_t lds = ptk_trace_lds_bytes(p.ntri);
         if (det_bounded && quads == 3 && PT_QUAD_PAIRS)
             hipLaunchKernelGGL((pt_trace_kernel<true, true, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else if (det_bounded && quads == 2 && PT_QUAD_PAIRS)
@@ -1259,8 +1338,9 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
         else
             hipLaunchKernelGGL((pt_trace_kernel<false, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), 0, s, p);
+        const size_t lds = ptk_trace_lds_bytes(p.ntri);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     }
     return hipGetLastError();
 }
@@ -1303,11 +1383,17 @@ hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s)
     return hipGetLastError();
 }
 
-int ptk_trace_blocks_per_cu(bool sorted)
+size_t ptk_trace_lds_bytes(int ntri)
+{
+    const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
+    return table + (size_t)(PT_TRACE_THREADS / 64) * PT_TRACE_BATCH * sizeof(float4);
+}
+
+int ptk_trace_blocks_per_cu(bool sorted, int ntri)
 {
     int nb = 0;
     hipError_t e = sorted ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_sorted_kernel<true>, PT_SORT_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, true>, PT_TRACE_THREADS, PT_LDS_TRI_MAX * PT_LDS_TRI_STRIDE * sizeof(float));
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
     if (e != hipSuccess || nb < 1) nb = sorted ? 1 : 2;
     return nb;
 }

@@ -210,8 +210,8 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
     }
-    d->blocks_per_cu = ptk_trace_blocks_per_cu(false);
-    d->blocks_per_cu_sorted = ptk_trace_blocks_per_cu(true);
+    d->blocks_per_cu = ptk_trace_blocks_per_cu(false, 36);
+    d->blocks_per_cu_sorted = ptk_trace_blocks_per_cu(true, 36);
     d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
     *out = d;
     return PT_OK;
@@ -651,6 +651,7 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->prep_p1_lo = -deltaP;
         d->prep_p1_hi = (delta1 + deltaP) * 1.001f;
     }
+    d->blocks_per_cu = ptk_trace_blocks_per_cu(false, ntri);  // the LDS footprint follows the scene
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
