@@ -71,8 +71,53 @@ def parse_meshes(blob: bytes):
     return meshes
 
 
-def load_model(path: str | None = None):
+def reference_material_table(n_meshes: int = 6, tags=None) -> list:
+    """The per-mesh materials RaytraceTest.cpp:145-176 hard-codes by mesh index, as data: a list of
+    ``{"albedo", "emissive", "roughness", "type"}`` dicts -- the format of a material side file."""
+    table = []
+    for i in range(n_meshes):
+        tag = np.float32(0.5) if tags is None else np.float32(tags[i])
+        m = {"albedo": [0.0, 0.0, 0.0, 0.0], "emissive": [0.0, 0.0, 0.0, 1.0], "roughness": 0.0, "type": "diffuse"}
+        if tag != np.float32(0.5):
+            m["emissive"] = [30.0, 30.0, 30.0, 1.0]
+            m["albedo"] = [1.0, 1.0, 1.0, 1.0]
+        if i in (0, 1, 2):
+            m["albedo"] = [0.7, 0.7, 0.7, 1.0]
+        if i == 3:
+            m["albedo"] = [0.6, 0.0, 0.0, 1.0]
+        if i == 4:
+            m["albedo"] = [0.0, 0.6, 0.0, 1.0]
+        if i == 5:
+            m["albedo"] = [0.5, 0.35, 0.05, 0.0]
+            m["roughness"] = 0.008
+            m["type"] = "specular"
+        table.append(m)
+    return table
+
+
+def _material_from_entry(e: dict) -> np.ndarray:
+    m = np.zeros((), MATERIAL_DTYPE)
+    kind = e.get("type", "diffuse")
+    if kind not in ("diffuse", "specular"):
+        raise ValueError("material type must be 'diffuse' or 'specular', got %r" % (kind,))
+    for key in ("albedo", "emissive"):
+        v = list(e.get(key, (0.0, 0.0, 0.0, 1.0)))
+        if len(v) == 3:
+            v.append(1.0)
+        if len(v) != 4:
+            raise ValueError("material %s needs 3 or 4 components" % key)
+        m[key] = tuple(float(x) for x in v)
+    m["roughness"] = float(e.get("roughness", 0.0))
+    m["type"] = SPECULAR if kind == "specular" else DIFFUSE
+    return m
+
+
+def load_model(path: str | None = None, materials=None):
     """Return ``(triangles, materials)`` as structured arrays (36 / 18 for the Cornell box).
+
+    ``materials``: None = the reference's hard-coded assignment (below); otherwise a per-mesh
+    table -- a list of dicts as :func:`reference_material_table` returns, or the path of a JSON file
+    holding such a list (materials from a side file instead of mesh-index ifs).
 
     Material assignment follows RaytraceTest.cpp:145-176: every mesh is DIFFUSE; a mesh whose
     tag != 0.5 is the light (emissive 30, albedo 1, then overridden to 0.7 for meshes 0-2);
@@ -82,27 +127,37 @@ def load_model(path: str | None = None):
     """
     with open(path or DEFAULT_SCENE, "rb") as f:
         meshes = parse_meshes(f.read())
+    if isinstance(materials, (str, os.PathLike)):
+        import json
+
+        with open(materials) as f:
+            materials = json.load(f)
+    if materials is not None and len(materials) != len(meshes):
+        raise ValueError("material table has %d entries for %d meshes" % (len(materials), len(meshes)))
     tris = []
     mats = []
     mat_id = 0
     for i, (tag, idx, vtx) in enumerate(meshes):
         m = np.zeros((), MATERIAL_DTYPE)
         m["type"] = DIFFUSE
-        if tag != np.float32(0.5):
+        if materials is not None:
+            m = _material_from_entry(materials[i])
+        elif tag != np.float32(0.5):
             m["emissive"] = (30.0, 30.0, 30.0, 1.0)
             m["albedo"] = (1.0, 1.0, 1.0, 1.0)
         else:
             m["emissive"] = (0.0, 0.0, 0.0, 1.0)
-        if i in (0, 1, 2):
-            m["albedo"] = (0.7, 0.7, 0.7, 1.0)
-        if i == 3:
-            m["albedo"] = (0.6, 0.0, 0.0, 1.0)
-        if i == 4:
-            m["albedo"] = (0.0, 0.6, 0.0, 1.0)
-        if i == 5:
-            m["albedo"] = (0.5, 0.35, 0.05, 0.0)
-            m["roughness"] = 0.008
-            m["type"] = SPECULAR
+        if materials is None:
+            if i in (0, 1, 2):
+                m["albedo"] = (0.7, 0.7, 0.7, 1.0)
+            if i == 3:
+                m["albedo"] = (0.6, 0.0, 0.0, 1.0)
+            if i == 4:
+                m["albedo"] = (0.0, 0.6, 0.0, 1.0)
+            if i == 5:
+                m["albedo"] = (0.5, 0.35, 0.05, 0.0)
+                m["roughness"] = 0.008
+                m["type"] = SPECULAR
         for a, b, c, d in idx:
             p = [np.array([vtx[k][0], vtx[k][1], vtx[k][2], 0.0], np.float32) for k in (a, b, c, d)]
             for q in ((p[0], p[1], p[2]), (p[2], p[3], p[0])):
@@ -185,3 +240,13 @@ def write_ppm(path: str, fb: np.ndarray, W: int, H: int) -> None:
     with open(path, "w") as f:
         f.write("P3\n%d %d\n%d\n" % (W, H, 255))
         f.write("".join("%d %d %d " % (r, g, b) for r, g, b in c))
+
+
+def write_ppm_binary(path: str, rgb: np.ndarray, W: int, H: int) -> None:
+    """Binary 'P6' PPM of the device tonemap's output (``pt_tonemap_ppm``: int32 r,g,b per pixel, the
+    values the reference prints as text).  One byte per channel: the reference's INT_MIN for a NaN /
+    overflowed pixel (RaytraceTest.cpp:78-83) has no byte representation and is written as 0."""
+    c = np.asarray(rgb).reshape(H * W, 3)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (W, H))
+        f.write(np.clip(c, 0, 255).astype(np.uint8).tobytes())

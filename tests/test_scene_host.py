@@ -75,3 +75,43 @@ def test_stripe_plan_partitions_rows(H, stripe, world):
         g = ((lr // stripe) * world + r) * stripe + lr % stripe
         assert np.array_equal(g, rows)
     assert plan.slab_rows == max(plan.local_rows(r) for r in range(world))
+
+
+def test_material_side_file_reproduces_reference_assignment(tmp_path):
+    """the per-mesh material ifs of RaytraceTest.cpp:145-176 as a data table."""
+    import json
+
+    base_t, base_m = scene.load_model()
+    meshes = scene.parse_meshes(open(scene.DEFAULT_SCENE, "rb").read())
+    table = scene.reference_material_table(len(meshes), [m[0] for m in meshes])
+    assert [e["type"] for e in table] == ["diffuse"] * 5 + ["specular"]
+    assert table[2]["emissive"][:3] == [30.0, 30.0, 30.0] and table[2]["albedo"][:3] == [0.7, 0.7, 0.7]  # the light
+    p = tmp_path / "materials.json"
+    p.write_text(json.dumps(table))
+    for src in (table, str(p)):
+        t, m = scene.load_model(materials=src)
+        assert t.tobytes() == base_t.tobytes() and m.tobytes() == base_m.tobytes()
+    # a different table changes the materials only
+    table[3]["albedo"] = [0.1, 0.2, 0.9]
+    table[4]["type"] = "specular"
+    table[4]["roughness"] = 0.25
+    t, m = scene.load_model(materials=table)
+    assert t.tobytes() == base_t.tobytes()
+    changed = [i for i in range(len(m)) if m[i].tobytes() != base_m[i].tobytes()]
+    assert changed == sorted(set(int(x) for x in t["id"][np.isin(t["id"], changed)]))
+    red_id = int(np.argmax(np.all(base_m["albedo"][:, :3] == np.array([0.6, 0, 0], np.float32), axis=1)))
+    assert np.allclose(m[red_id]["albedo"], [0.1, 0.2, 0.9, 1.0])
+    green_id = int(np.argmax(np.all(base_m["albedo"][:, :3] == np.array([0, 0.6, 0], np.float32), axis=1)))
+    assert m[green_id]["type"] == scene.SPECULAR and m[green_id]["roughness"] == np.float32(0.25)
+    with pytest.raises(ValueError):
+        scene.load_model(materials=table[:3])
+    table[0]["type"] = "glass"
+    with pytest.raises(ValueError):
+        scene.load_model(materials=table)
+
+
+def test_binary_ppm(tmp_path):
+    rgb = np.array([[0, 127, 255], [255, 255, 255], [51, 76, 102], [-2147483648, 300, 7]], np.int32)
+    p = tmp_path / "o6.ppm"
+    scene.write_ppm_binary(str(p), rgb, 2, 2)
+    assert p.read_bytes() == b"P6\n2 2\n255\n" + bytes([0, 127, 255, 255, 255, 255, 51, 76, 102, 0, 255, 7])
