@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="trace kernel: 0 library default, 1 lane-regenerating, 2 octant-sorted")
     ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 2 pairs, 3 shared u, 4 packed")
+    ap.add_argument("--accel", type=int, default=0, help="PT_OPT_ACCEL: 0 auto (LBVH from 512 triangles), 1 brute force, 2 LBVH")
+    ap.add_argument("--soup", type=int, default=0, help="render the synthetic N-triangle soup of BASELINE configs[4] (Cornell box + "
+                    "N-36 small triangles) instead of cornellbox.bin; exploration only: no roofline / cpu_baseline objects")
     args = ap.parse_args()
 
     import torch  # first: the shim must bind to the HIP runtime torch already loaded
@@ -139,7 +142,7 @@ def main():
     from oclpathtracer_amd import adl, scene, shim
     from oclpathtracer_amd.distributed import StripeImage
 
-    tris, mats = scene.load_model()
+    tris, mats = scene.make_soup(args.soup) if args.soup else scene.load_model()
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
 
     assert adl.init(adl.TYPE_HIP), "adl.init failed"
@@ -147,6 +150,7 @@ def main():
     lib = shim.load()
     dev.setOption(shim.PT_OPT_TRACE_VARIANT, args.variant)
     dev.setOption(shim.PT_OPT_QUAD_FILTER, args.quad_filter)
+    dev.setOption(shim.PT_OPT_ACCEL, args.accel)
     img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True)
 
     def step():
@@ -199,6 +203,21 @@ def main():
                        "sharding": "%d-row image stripes round-robin over %d rank(s), RCCL gather to rank 0" % (args.stripe_rows, world),
                        "rays_per_sample": total_rays / total_samples},
         }
+        if args.soup:
+            out["metric"] = "Msamples/sec (pixels x spp / s), %d-triangle soup %dx%d" % (len(tris), W, H)
+            out["config"]["workload"] = "soup of %d triangles (BASELINE configs[4] generator) %dx%d, %d spp, depth %d, accel %d" % (
+                len(tris), W, H, spp, depth, args.accel)
+            out["roofline"] = None
+            out["kernels"] = {"pt_trace_kernel_ms_total": tot_ms.value, "pt_trace_kernel_launches": int(launches.value),
+                              "pt_fold_kernel_ms_total": fold_ms.value}
+            print(json.dumps(out))
+            sys.stdout.flush()
+            img.release()
+            adl.DeviceUtils.deallocate(dev)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         cpu, tallies = (None, None)
         if world == 1 and not args.no_cpu_baseline:
             cpu, tallies = cpu_baseline(tris, mats, depth)

@@ -110,7 +110,14 @@ enum pt_option {
      * pair filter (shared cross product), 3 = at most the shared-u filter (one numerator decides
      * both triangles of an (a,b,c),(c,d,a) pair), 4 = at most its packed Pluecker form (two quads
      * per instruction).  All settings produce identical pixels. */
-    PT_OPT_QUAD_FILTER = 4
+    PT_OPT_QUAD_FILTER = 4,
+    /* closest-hit search: 0 = brute force below 512 triangles, LBVH from 512 on;
+     * 1 = brute force (the reference's intersectWorld loop, GenerateColors.cl:137-154); 2 = LBVH
+     * (built on the GPU when the scene is first rendered; scenes of >= 2 triangles).  The LBVH
+     * applies the same exact triangle test to a conservative candidate set and resolves ties to the
+     * lower index, as the reference's ascending loop does; see csrc/pt_bvh.hip for the one
+     * theoretical caveat (rays within ~0.05 degrees of a triangle's plane). */
+    PT_OPT_ACCEL = 5
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

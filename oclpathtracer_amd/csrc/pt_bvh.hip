@@ -1,0 +1,223 @@
+// pt_bvh.hip -- LBVH over the scene's triangles, built on the GPU at scene upload (gfx950 only).
+//
+// The reference finds the closest hit by brute force (intersectWorld, GenerateColors.cl:137-154);
+// SURVEY S8f rank 3 replaces the O(N) loop for large scenes.  The closest hit is order-free: the
+// winner of the reference's ascending loop with its strict `t < tmax` (:125) is argmin (t, index)
+// over the triangles whose exact test passes, so ANY traversal that applies the same exact test
+// (pt_tri_pass2's arithmetic) to a superset of those triangles and keeps the lexicographic minimum
+// returns the same (t, u, v, index) bit for bit.  The hierarchy only has to be conservative: a
+// node is skipped when the ray misses its box grown by PT_BVH_EPS x (largest |coordinate|).
+// (A binary32 Moeller-Trumbore test can accept a hit that lies outside the triangle by
+// ~1e-6 x distance / cos(incidence); for rays within ~0.05 degrees of a triangle's plane that
+// displacement is unbounded, so no finite box margin is PROVABLY conservative.  The margin covers
+// cos(incidence) >= 1e-2 with a factor 10 to spare; tests compare against brute force.)
+//
+// Build (Karras 2012): 30-bit Morton code of the box centre | triangle index -> 64-bit keys,
+// hipcub radix sort, one thread per internal node finds its range and split, bottom-up box refit
+// with one atomic flag per internal node, then "miss links" so that traversal needs no stack:
+//     node = root;  while (node >= 0):  hit box ? (leaf ? test triangle, node = miss : node = left) : node = miss
+#include "pt_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#define PT_BVH_EPS 1.2e-4f
+
+namespace {
+
+__device__ __forceinline__ unsigned pt_ordered(float f)
+{
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b ^ 0x80000000u);  // unsigned order == float order
+}
+__device__ __forceinline__ float pt_unordered(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+__device__ __forceinline__ bool pt_tri_box(const PtRawTriangle& t, float lo[3], float hi[3])
+{
+    bool finite = true;
+    for (int k = 0; k < 3; ++k) {
+        const float a = t.p1[k], b = t.p2[k], c = t.p3[k];
+        finite = finite && __builtin_isfinite(a) && __builtin_isfinite(b) && __builtin_isfinite(c);
+        lo[k] = fminf(a, fminf(b, c));
+        hi[k] = fmaxf(a, fmaxf(b, c));
+    }
+    return finite;
+}
+
+// bounds[0..2] = min, [3..5] = max of the finite triangles' boxes, [6] = largest |coordinate| (ordered keys)
+__global__ void pt_bvh_bounds_kernel(const PtRawTriangle* __restrict__ raw, int ntri, unsigned* __restrict__ bounds)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntri) return;
+    float lo[3], hi[3];
+    if (!pt_tri_box(raw[i], lo, hi)) return;  // a triangle with a non-finite vertex is never hit (t is NaN or Inf)
+    float m = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        atomicMin(&bounds[k], pt_ordered(lo[k]));
+        atomicMax(&bounds[3 + k], pt_ordered(hi[k]));
+        m = fmaxf(m, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    }
+    atomicMax(&bounds[6], pt_ordered(m));
+}
+
+__device__ __forceinline__ unsigned pt_expand10(unsigned v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void pt_bvh_keys_kernel(const PtRawTriangle* __restrict__ raw, int ntri, const unsigned* __restrict__ bounds,
+                                   unsigned long long* __restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntri) return;
+    float lo[3], hi[3];
+    unsigned code = 0x3fffffffu;  // non-finite triangles sort to the end
+    if (pt_tri_box(raw[i], lo, hi)) {
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float smin = pt_unordered(bounds[k]), smax = pt_unordered(bounds[3 + k]);
+            const float ext = smax - smin;
+            float c = ext > 0.0f ? (0.5f * (lo[k] + hi[k]) - smin) / ext : 0.0f;
+            c = fminf(fmaxf(c * 1024.0f, 0.0f), 1023.0f);
+            q[k] = (unsigned)c;
+        }
+        code = (pt_expand10(q[0]) << 2) | (pt_expand10(q[1]) << 1) | pt_expand10(q[2]);
+    }
+    keys[i] = ((unsigned long long)code << 32) | (unsigned)i;
+}
+
+// length of the common prefix of keys i and j (keys are unique), -1 outside [0, n)
+__device__ __forceinline__ int pt_delta(const unsigned long long* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// nodes: internal i in [0, n-1), leaf k at n-1+k.  parent[] for every node, -1 for the root.
+__global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ keys, int n, PtBvhNode* __restrict__ nodes,
+                                        int* __restrict__ parent, int* __restrict__ right_child)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = pt_delta(keys, n, i, i + 1) - pt_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = pt_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (pt_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (pt_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = pt_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (pt_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int left = lo == gamma ? n - 1 + gamma : gamma;
+    const int right = hi == gamma + 1 ? n - 1 + gamma + 1 : gamma + 1;
+    nodes[i].link = (unsigned)left;
+    right_child[i] = right;
+    parent[left] = i;
+    parent[right] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+__global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ keys, int n,
+                                    const unsigned* __restrict__ bounds, PtBvhNode* __restrict__ nodes,
+                                    const int* __restrict__ parent, const int* __restrict__ right_child, int* __restrict__ flags)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int tri = (int)(unsigned)keys[k];
+    const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
+    float lo[3], hi[3];
+    PtBvhNode leaf;
+    if (pt_tri_box(raw[tri], lo, hi)) {
+        for (int a = 0; a < 3; ++a) { leaf.bmin[a] = lo[a] - eps; leaf.bmax[a] = hi[a] + eps; }
+    } else {
+        for (int a = 0; a < 3; ++a) { leaf.bmin[a] = 3.0e38f; leaf.bmax[a] = -3.0e38f; }  // empty: never entered
+    }
+    leaf.link = 0x80000000u | (unsigned)tri;
+    leaf.miss = -1;
+    int node = n - 1 + k;
+    nodes[node].bmin[0] = leaf.bmin[0]; nodes[node].bmin[1] = leaf.bmin[1]; nodes[node].bmin[2] = leaf.bmin[2];
+    nodes[node].bmax[0] = leaf.bmax[0]; nodes[node].bmax[1] = leaf.bmax[1]; nodes[node].bmax[2] = leaf.bmax[2];
+    nodes[node].link = leaf.link;
+    // climb: the second child to arrive at a node unions the two boxes and continues
+    // (a radix tree over 64-bit keys is at most 64 levels deep: the cap only guards against a damaged tree)
+    int guard = 0;
+    for (int p = parent[node]; p >= 0 && guard < 80; p = parent[p], ++guard) {
+        __threadfence();
+        if (atomicAdd(&flags[p], 1) == 0) return;
+        __threadfence();
+        const int l = (int)nodes[p].link, r = right_child[p];
+        for (int a = 0; a < 3; ++a) {
+            // volatile-style reads through atomics are not needed: the fence above orders the sibling's stores
+            nodes[p].bmin[a] = fminf(nodes[l].bmin[a], nodes[r].bmin[a]);
+            nodes[p].bmax[a] = fmaxf(nodes[l].bmax[a], nodes[r].bmax[a]);
+        }
+    }
+}
+
+// miss link: where traversal continues after this node's subtree = the right sibling of the nearest
+// ancestor-or-self that is a left child; -1 at the end of the traversal
+__global__ void pt_bvh_links_kernel(int n, PtBvhNode* __restrict__ nodes, const int* __restrict__ parent,
+                                    const int* __restrict__ right_child)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= 2 * n - 1) return;
+    int c = x, miss = -1, guard = 0;
+    for (int p = parent[c]; p >= 0 && guard < 80; c = p, p = parent[p], ++guard) {
+        if (right_child[p] != c) { miss = right_child[p]; break; }
+    }
+    nodes[x].miss = miss;
+}
+
+}  // namespace
+
+size_t ptk_bvh_node_count(int ntri) { return ntri > 0 ? (size_t)2 * ntri - 1 : 0; }
+
+size_t ptk_bvh_temp_bytes(int ntri)
+{
+    size_t cub = 0;
+    unsigned long long* nullk = nullptr;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
+    const size_t n = (size_t)ntri;
+    // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[8], cub temp
+    return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024;
+}
+
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
+    const size_t n = (size_t)ntri;
+    char* p = (char*)temp;
+    unsigned long long* keys = (unsigned long long*)p; p += 8 * n;
+    unsigned long long* sorted = (unsigned long long*)p; p += 8 * n;
+    int* parent = (int*)p; p += 4 * 2 * n;
+    int* right_child = (int*)p; p += 4 * n;
+    int* flags = (int*)p; p += 4 * n;
+    unsigned* bounds = (unsigned*)p; p += 64;
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    size_t cub = temp_bytes - (size_t)(p - (char*)temp);
+    const unsigned init[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0x80000000u /* ordered(0) */, 0u };
+    hipError_t e = hipMemcpyAsync(bounds, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(flags, 0, 4 * n, s)) != hipSuccess) return e;
+    const dim3 blk(256), grd((ntri + 255) / 256);
+    hipLaunchKernelGGL(pt_bvh_bounds_kernel, grd, blk, 0, s, raw, ntri, bounds);
+    hipLaunchKernelGGL(pt_bvh_keys_kernel, grd, blk, 0, s, raw, ntri, bounds, keys);
+    if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, grd, blk, 0, s, sorted, ntri, nodes, parent, right_child);
+    hipLaunchKernelGGL(pt_bvh_refit_kernel, grd, blk, 0, s, raw, sorted, ntri, bounds, nodes, parent, right_child, flags);
+    hipLaunchKernelGGL(pt_bvh_links_kernel, dim3((2 * ntri - 1 + 255) / 256), blk, 0, s, ntri, nodes, parent, right_child);
+    return hipGetLastError();
+}

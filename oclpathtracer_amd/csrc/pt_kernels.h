@@ -24,6 +24,11 @@ struct PtPrepTriangle {
 };
 static_assert(sizeof(PtPrepTriangle) == 64, "prep layout");
 
+// LBVH node (pt_bvh.hip): its own box, link = left child (internal) or 0x80000000 | triangle (leaf),
+// miss = where a stackless traversal continues after this subtree (-1 = done)
+struct PtBvhNode { float bmin[3]; uint32_t link; float bmax[3]; int32_t miss; };
+static_assert(sizeof(PtBvhNode) == 32, "bvh node layout");
+
 #define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
 #define PT_LDS_TRI_STRIDE 12    // dwords per triangle record in the LDS copy (p1, e1, e2, 3 pad)
@@ -49,6 +54,7 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
+    const PtBvhNode* bvh;         // accel = BVH: 2*ntri-1 nodes, root 0
 };
 
 struct PtFoldParams {
@@ -75,8 +81,13 @@ static inline size_t ptk_p1tab_floats(int ntri) { return (size_t)((ntri / 2 + 1)
 // quads: 0 = none; 1 = ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1);
 //        2 = additionally p1' == p3 and the margins are prepared (pt_quad2_pass1)
 //        3 = as 2, evaluated from the packed table p.p1tab (pt_quad3_pass1)
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, hipStream_t s);
+// bvh: traverse p.bvh instead of the brute-force two-pass search (variant 1 only)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, bool bvh, hipStream_t s);
+size_t ptk_bvh_node_count(int ntri);
+size_t ptk_bvh_temp_bytes(int ntri);
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, void* temp, size_t temp_bytes, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
+#define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 #ifndef PT_DEFAULT_SORTED
 #define PT_DEFAULT_SORTED 0  // which variant PT_OPT_TRACE_VARIANT = 0 (auto) picks
 #endif

@@ -622,6 +622,79 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
     return steps;
 }
 
+// ---- closest hit through the LBVH (pt_bvh.hip) -----------------------------------------------------
+// Stackless traversal along the nodes' miss links; every lane walks its own ray.  At a leaf the
+// reference's exact test runs with pt_tri_pass2's arithmetic; because leaves are met in tree order,
+// not index order, the reference's "first triangle wins an exact tie" (:125 with ascending i)
+// becomes: accept when t < tmax, or t == tmax and the index is lower than the holder's.
+#define PT_ACCEL_BVH (-1)  // value of the trace kernel's QUADS parameter that selects this search
+
+template <bool DET_BOUNDED>
+PTK_DEV void pt_tri_exact_unordered(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
+{
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    float inv_det = DET_BOUNDED ? pt_rcp(det) : 1.0f / det;  // pt_rcp: exact, range-checked (det may be anything here)
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+    bool ok = !(det < 1e-8f) & !(-det > 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109
+    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
+    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
+    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
+    ok &= (tt > 0.0f) & ((tt < tmax) | ((tt == tmax) & (i < hidx)));  // :125 in any visiting order
+    tmax = ok ? tt : tmax;
+    hu = ok ? u : hu;
+    hv = ok ? v : hv;
+    hidx = ok ? i : hidx;
+}
+
+template <bool DET_BOUNDED>
+PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepTriangle* __restrict__ tris, int ntri, const f3& o, const f3& d,
+                              bool alive, float& tmax, float& hu, float& hv, int& hidx)
+{
+    // 1/dir for the slab test only (conservative boxes: the approximation error of v_rcp_f32 is far
+    // inside the boxes' margin); a zero component gives +-Inf and (b - o) * Inf = +-Inf or NaN, and
+    // v_min/v_max drop NaNs: that axis then constrains nothing
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    int node = alive ? 0 : -1;
+    // a traversal meets each of the 2n-1 nodes at most once: the budget and the index check make a
+    // damaged hierarchy end the search instead of hanging or faulting the GPU
+    const unsigned n_nodes = 2u * (unsigned)ntri - 1u;
+    for (unsigned budget = n_nodes + 1u; budget != 0u && __ballot(node >= 0) != 0ull; --budget) {
+        if ((unsigned)node < n_nodes) {
+            const float4 a = *reinterpret_cast<const float4*>(&nodes[node]);      // bmin.xyz, link
+            const float4 b = *(reinterpret_cast<const float4*>(&nodes[node]) + 1);  // bmax.xyz, miss
+            const float t1x = (a.x - o.x) * ix, t2x = (b.x - o.x) * ix;
+            const float t1y = (a.y - o.y) * iy, t2y = (b.y - o.y) * iy;
+            const float t1z = (a.z - o.z) * iz, t2z = (b.z - o.z) * iz;
+            const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+            const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+            // a NaN ray or box fails these and the subtree is skipped: nothing in it could be accepted
+            // (a NaN in o or d makes every t NaN; NaN boxes do not exist, non-finite triangles get empty ones)
+            const bool hit = (tnear <= tfar) & (tfar >= 0.0f) & (tnear <= tmax);
+            const unsigned link = __float_as_uint(a.w);
+            int next = __float_as_int(b.w);
+            if (hit) {
+                if (link & 0x80000000u) {
+                    const int i = (int)(link & 0x7fffffffu);
+                    const PtTriRec r = pt_fetch_rec<false>(tris, i);
+                    pt_tri_exact_unordered<DET_BOUNDED>(r, i, o, d, tmax, hu, hv, hidx);
+                } else {
+                    next = (int)link;
+                }
+            }
+            node = next;
+        } else {
+            node = -1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // trace kernels
 // ------------------------------------------------------------------------------------------
@@ -976,7 +1049,11 @@ void pt_trace_kernel(const PtTraceParams P)
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
 #if PT_TWO_PASS
-        const unsigned p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
+        unsigned p2steps = 0;
+        if (QUADS == PT_ACCEL_BVH)
+            pt_intersect_bvh<DET_BOUNDED>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
+        else
+            p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
                                                                                           (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi,
                                                                                           PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr,
@@ -1320,8 +1397,14 @@ hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, 
     return hipGetLastError();
 }
 
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, hipStream_t s)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, bool bvh, hipStream_t s)
 {
+    if (bvh && !sorted) {
+        const size_t lds = ptk_trace_lds_bytes(PT_LDS_TRI_MAX + 1);  // camera slots only
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, PT_ACCEL_BVH>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, false, PT_ACCEL_BVH>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        return hipGetLastError();
+    }
     if (sorted) {
         if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
         else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);

@@ -83,7 +83,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -95,6 +95,8 @@ struct pt_device_s {
     int prep_quads;             // 0: no pair structure; 1: every pair (2k, 2k+1) has e2' == -e2;
                                 // 2: additionally p1' == p3, finite radius, margins prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
+    PtBvhNode* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
+    bool bvh_valid;
     float* p1tab;               // quad mode 3: packed pass-1 table (pt_quad3_pass1), sized with prep
     float prep_p1_lo, prep_p1_hi;
     unsigned int* det_bound_dev;  // PT_PREP_WORDS device words written by the prep kernel
@@ -201,6 +203,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_profile = 0;
     d->opt_variant = 0;
     d->opt_quads = 0;
+    d->opt_accel = 0;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
@@ -229,6 +232,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
         return fail(PT_ERR_INVALID, "%d buffer(s) of this device are still alive", d->live_buffers);
     if (d->prep) hipFree(d->prep);
     if (d->p1tab) hipFree(d->p1tab);
+    if (d->bvh) hipFree(d->bvh);
     if (d->rad) hipFree(d->rad);
     if (d->counters) hipFree(d->counters);
     if (d->det_bound_dev) hipFree(d->det_bound_dev);
@@ -324,6 +328,10 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
         if (value < 0 || value > 4) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1 (off), 2 (pairs), 3 (shared u) or 4 (packed shared u)");
         d->opt_quads = value;
         return PT_OK;
+    case PT_OPT_ACCEL:
+        if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "accel must be 0 (auto), 1 (brute force) or 2 (BVH)");
+        d->opt_accel = value;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -337,6 +345,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_PROFILE_RETURN_TIME: return d->opt_profile;
     case PT_OPT_TRACE_VARIANT: return d->opt_variant;
     case PT_OPT_QUAD_FILTER: return d->opt_quads;
+    case PT_OPT_ACCEL: return d->opt_accel;
     default: return -1;
     }
 }
@@ -612,8 +621,11 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         HIP_TRY(hipStreamSynchronize(d->stream));
         if (d->prep) hipFree(d->prep);
         if (d->p1tab) hipFree(d->p1tab);
+        if (d->bvh) hipFree(d->bvh);
         d->prep = nullptr;
         d->p1tab = nullptr;
+        d->bvh = nullptr;
+        d->bvh_valid = false;
         d->prep_capacity = 0;
         size_t cap = std::max<size_t>((size_t)ntri, 64);
         hipError_t e = hipMalloc(&d->prep, cap * sizeof(PtPrepTriangle));
@@ -652,9 +664,31 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->prep_p1_hi = (delta1 + deltaP) * 1.001f;
     }
     d->blocks_per_cu = ptk_trace_blocks_per_cu(false, ntri);  // the LDS footprint follows the scene
+    d->bvh_valid = false;
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
+    return PT_OK;
+}
+
+// LBVH of the current prepared scene: built on the GPU the first time a render
+// of this scene wants it (PT_OPT_ACCEL), kept until the scene changes
+static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
+{
+    if (d->bvh_valid) return PT_OK;
+    if (!d->bvh) {
+        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvhNode));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e)); }
+    }
+    const size_t temp_bytes = ptk_bvh_temp_bytes(ntri);
+    void* temp = nullptr;
+    hipError_t e = hipMalloc(&temp, temp_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH build workspace allocation failed: %s", hipGetErrorString(e)); }
+    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, ntri, d->bvh, temp, temp_bytes, d->stream);
+    hipError_t e2 = hipStreamSynchronize(d->stream);  // once per scene upload; the workspace is freed right after
+    hipFree(temp);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    d->bvh_valid = true;
     return PT_OK;
 }
 
@@ -694,6 +728,10 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     if (rc) return rc;
     if (npix == 0 || rp.frame_count == 0) return event_end(d, ev);
     if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
+    // PT_OPT_ACCEL: 0 = BVH for scenes of PT_BVH_AUTO_MIN triangles or more, 1 = brute force, 2 = BVH (needs >= 2 triangles)
+    const bool use_bvh = d->opt_variant != 2 && rp.num_triangles >= 2 &&
+                         (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
+    if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
 
     // frames per chunk: radiance staging is 16 B x pixels x frames
     // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
@@ -757,6 +795,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1tab = d->p1tab;
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
+        tp.bvh = d->bvh;
         // PT_OPT_QUAD_FILTER: 0 = best the scene allows, k = at most mode k-1
         const int quads = d->opt_quads ? std::min(d->prep_quads, (int)d->opt_quads - 1) : d->prep_quads;
         // persistent grid: fill the chip, but never more waves than batches
@@ -768,7 +807,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, sorted, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, sorted, use_bvh, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;

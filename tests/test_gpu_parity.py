@@ -310,3 +310,57 @@ def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
         device.setOption(shim.PT_OPT_QUAD_FILTER, 0)
     assert_fb_equal(got, want, kind)
     assert gst["rays"] == st["rays"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,ntri", [("cornell", 36), ("soup", 300), ("soup", 2000), ("soup", 20000), ("degenerate", 36),
+                                        ("pairs_broken", 36), ("quads_far", 36)])
+def test_bvh_matches_oracle(device, oracle, kind, ntri):
+    """PT_OPT_ACCEL = 2: the LBVH closest-hit search against the brute-force oracle.
+    Asserted bit for bit -- what the order-free argmin (t, index) argument gives whenever no accepted hit
+    lies outside its triangle's grown box; north_star's tolerance (RMS 1e-4) is the documented bar for
+    the near-parallel rays that argument cannot cover (csrc/pt_bvh.hip)."""
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    if kind == "cornell":
+        tris, mats = scene.load_model()
+    elif kind == "soup":
+        tris, mats = scene.make_soup(ntri)
+    else:
+        tris, mats = _variant_scene(kind)
+    W, H, frames = (64, 48, 3) if ntri <= 2000 else (48, 32, 2)
+    want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
+    device.setOption(shim.PT_OPT_ACCEL, 2)
+    r = Renderer(device, tris, mats, W, H, want_stats=True)
+    try:
+        r.render(frames)
+        got = r.read()
+        gst = r.read_stats()
+    finally:
+        r.release()
+        device.setOption(shim.PT_OPT_ACCEL, 0)
+    assert rms_diff(got, want) <= 1e-4
+    assert_fb_equal(got, want, "bvh %s %d" % (kind, ntri))
+    assert gst["rays"] == st["rays"]
+
+
+def test_bvh_matches_gpu_brute_force_200k_triangles(device):
+    """A soup too large for the CPU oracle: the LBVH against the brute-force kernel on the same GPU."""
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = scene.make_soup(200_000)
+    W, H, frames = 64, 32, 2
+    out = {}
+    for accel in (1, 2):
+        device.setOption(shim.PT_OPT_ACCEL, accel)
+        r = Renderer(device, tris, mats, W, H, want_stats=True)
+        try:
+            r.render(frames)
+            out[accel] = (r.read(), r.read_stats())
+        finally:
+            r.release()
+            device.setOption(shim.PT_OPT_ACCEL, 0)
+    assert_fb_equal(out[2][0], out[1][0], "bvh vs brute force, 200k triangles")
+    assert out[2][1]["rays"] == out[1][1]["rays"]
