@@ -14,8 +14,10 @@
 //
 // Build (Karras 2012): 30-bit Morton code of the box centre | triangle index -> 64-bit keys,
 // hipcub radix sort, one thread per internal node finds its range and split, bottom-up box refit
-// with one atomic flag per internal node, then "miss links" so that traversal needs no stack:
-//     node = root;  while (node >= 0):  hit box ? (leaf ? test triangle, node = miss : node = left) : node = miss
+// with one atomic flag per internal node.  Only the n-1 internal nodes are stored: a 64-byte record
+// holds BOTH children's boxes and links (a leaf is a link with the top bit set, carrying the
+// triangle index), so one fetch decides which child is nearer (pt_intersect_bvh: near child first,
+// far child on a per-lane stack).
 #include "pt_kernels.h"
 
 #include <hipcub/hipcub.hpp>
@@ -123,7 +125,9 @@ __global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ k
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     const int left = lo == gamma ? n - 1 + gamma : gamma;
     const int right = hi == gamma + 1 ? n - 1 + gamma + 1 : gamma + 1;
-    nodes[i].link = (unsigned)left;
+    // links: internal child = its index; leaf child = 0x80000000 | triangle (keys carry the index)
+    nodes[i].link_l = left >= n - 1 ? 0x80000000u | (unsigned)keys[left - (n - 1)] : (unsigned)left;
+    nodes[i].link_r = right >= n - 1 ? 0x80000000u | (unsigned)keys[right - (n - 1)] : (unsigned)right;
     right_child[i] = right;
     parent[left] = i;
     parent[right] = i;
@@ -131,7 +135,7 @@ __global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ k
 }
 
 __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ keys, int n,
-                                    const unsigned* __restrict__ bounds, PtBvhNode* __restrict__ nodes,
+                                    const unsigned* __restrict__ bounds, PtBvhNode* nodes,
                                     const int* __restrict__ parent, const int* __restrict__ right_child, int* __restrict__ flags)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,51 +143,36 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     const int tri = (int)(unsigned)keys[k];
     const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
     float lo[3], hi[3];
-    PtBvhNode leaf;
     if (pt_tri_box(raw[tri], lo, hi)) {
-        for (int a = 0; a < 3; ++a) { leaf.bmin[a] = lo[a] - eps; leaf.bmax[a] = hi[a] + eps; }
+        for (int a = 0; a < 3; ++a) { lo[a] -= eps; hi[a] += eps; }
     } else {
-        for (int a = 0; a < 3; ++a) { leaf.bmin[a] = 3.0e38f; leaf.bmax[a] = -3.0e38f; }  // empty: never entered
+        for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }  // empty: never entered
     }
-    leaf.link = 0x80000000u | (unsigned)tri;
-    leaf.miss = -1;
+    // climb: a child stores its box in its parent's record; the second child to arrive unions the two
+    // and carries the result one level up.  (A radix tree over 64-bit keys is at most 64 levels deep:
+    // the cap only guards against a damaged tree.)
     int node = n - 1 + k;
-    nodes[node].bmin[0] = leaf.bmin[0]; nodes[node].bmin[1] = leaf.bmin[1]; nodes[node].bmin[2] = leaf.bmin[2];
-    nodes[node].bmax[0] = leaf.bmax[0]; nodes[node].bmax[1] = leaf.bmax[1]; nodes[node].bmax[2] = leaf.bmax[2];
-    nodes[node].link = leaf.link;
-    // climb: the second child to arrive at a node unions the two boxes and continues
-    // (a radix tree over 64-bit keys is at most 64 levels deep: the cap only guards against a damaged tree)
-    int guard = 0;
-    for (int p = parent[node]; p >= 0 && guard < 80; p = parent[p], ++guard) {
+    for (int guard = 0; guard < 80; ++guard) {
+        const int p = parent[node];
+        if (p < 0) return;
+        float* slot_min = right_child[p] == node ? nodes[p].rmin : nodes[p].lmin;
+        float* slot_max = right_child[p] == node ? nodes[p].rmax : nodes[p].lmax;
+        for (int a = 0; a < 3; ++a) { slot_min[a] = lo[a]; slot_max[a] = hi[a]; }
         __threadfence();
         if (atomicAdd(&flags[p], 1) == 0) return;
         __threadfence();
-        const int l = (int)nodes[p].link, r = right_child[p];
+        const volatile PtBvhNode* q = &nodes[p];  // the sibling's stores, made visible by the fences
         for (int a = 0; a < 3; ++a) {
-            // volatile-style reads through atomics are not needed: the fence above orders the sibling's stores
-            nodes[p].bmin[a] = fminf(nodes[l].bmin[a], nodes[r].bmin[a]);
-            nodes[p].bmax[a] = fmaxf(nodes[l].bmax[a], nodes[r].bmax[a]);
+            lo[a] = fminf(q->lmin[a], q->rmin[a]);
+            hi[a] = fmaxf(q->lmax[a], q->rmax[a]);
         }
+        node = p;
     }
-}
-
-// miss link: where traversal continues after this node's subtree = the right sibling of the nearest
-// ancestor-or-self that is a left child; -1 at the end of the traversal
-__global__ void pt_bvh_links_kernel(int n, PtBvhNode* __restrict__ nodes, const int* __restrict__ parent,
-                                    const int* __restrict__ right_child)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= 2 * n - 1) return;
-    int c = x, miss = -1, guard = 0;
-    for (int p = parent[c]; p >= 0 && guard < 80; c = p, p = parent[p], ++guard) {
-        if (right_child[p] != c) { miss = right_child[p]; break; }
-    }
-    nodes[x].miss = miss;
 }
 
 }  // namespace
 
-size_t ptk_bvh_node_count(int ntri) { return ntri > 0 ? (size_t)2 * ntri - 1 : 0; }
+size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ntri - 1 : 0; }
 
 size_t ptk_bvh_temp_bytes(int ntri)
 {
@@ -218,6 +207,5 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, v
     if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, grd, blk, 0, s, sorted, ntri, nodes, parent, right_child);
     hipLaunchKernelGGL(pt_bvh_refit_kernel, grd, blk, 0, s, raw, sorted, ntri, bounds, nodes, parent, right_child, flags);
-    hipLaunchKernelGGL(pt_bvh_links_kernel, dim3((2 * ntri - 1 + 255) / 256), blk, 0, s, ntri, nodes, parent, right_child);
     return hipGetLastError();
 }

@@ -24,10 +24,15 @@ struct PtPrepTriangle {
 };
 static_assert(sizeof(PtPrepTriangle) == 64, "prep layout");
 
-// LBVH node (pt_bvh.hip): its own box, link = left child (internal) or 0x80000000 | triangle (leaf),
-// miss = where a stackless traversal continues after this subtree (-1 = done)
-struct PtBvhNode { float bmin[3]; uint32_t link; float bmax[3]; int32_t miss; };
-static_assert(sizeof(PtBvhNode) == 32, "bvh node layout");
+// LBVH internal node (pt_bvh.hip): the boxes of BOTH children and their links; a link is the child's
+// node index, or 0x80000000 | triangle index for a leaf.  64 bytes = four 16-byte loads.
+struct PtBvhNode {
+    float lmin[3]; uint32_t link_l;
+    float lmax[3]; uint32_t link_r;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
 #define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
@@ -54,7 +59,7 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvhNode* bvh;         // accel = BVH: 2*ntri-1 nodes, root 0
+    const PtBvhNode* bvh;         // accel = BVH: ntri-1 internal nodes, root 0
 };
 
 struct PtFoldParams {

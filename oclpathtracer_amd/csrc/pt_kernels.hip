@@ -653,46 +653,88 @@ PTK_DEV void pt_tri_exact_unordered(const PtTriRec& r, int i, const f3& o, const
     hidx = ok ? i : hidx;
 }
 
+// slab test of one box; NaNs (a zero direction component against a coincident plane) are dropped by
+// v_min/v_max, so that axis constrains nothing.  Returns the entry distance in tn.
+PTK_DEV bool pt_slab(const float4& bmin, const float4& bmax, const f3& o, float ix, float iy, float iz, float tmax, float& tn)
+{
+    const float t1x = (bmin.x - o.x) * ix, t2x = (bmax.x - o.x) * ix;
+    const float t1y = (bmin.y - o.y) * iy, t2y = (bmax.y - o.y) * iy;
+    const float t1z = (bmin.z - o.z) * iz, t2z = (bmax.z - o.z) * iz;
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+    // a NaN ray fails these: nothing could be accepted for it anyway (every t is NaN)
+    return (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);
+}
+
+// Near-child-first traversal with a per-lane stack of far children (private memory: one entry per
+// level at most, and a radix tree over 64-bit keys has at most 64 levels).  Leaves are tested as
+// soon as their box is hit; tmax then prunes everything farther.
+#define PT_BVH_STACK 64
 template <bool DET_BOUNDED>
 PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepTriangle* __restrict__ tris, int ntri, const f3& o, const f3& d,
-                              bool alive, float& tmax, float& hu, float& hv, int& hidx)
+                              bool alive, float& tmax, float& hu, float& hv, int& hidx, unsigned long long* bstat = nullptr)
 {
-    // 1/dir for the slab test only (conservative boxes: the approximation error of v_rcp_f32 is far
-    // inside the boxes' margin); a zero component gives +-Inf and (b - o) * Inf = +-Inf or NaN, and
-    // v_min/v_max drop NaNs: that axis then constrains nothing
+#ifndef PT_BVH_STATS
+#define PT_BVH_STATS 0  // DIAGNOSTIC build: stats[2..5] = nodes entered, leaves tested, wave loop iterations, rays
+#endif
+    (void)bstat;
+    unsigned c_nodes = 0, c_leaves = 0, c_iters = 0;
+    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
+    // boxes' margin); a zero component gives +-Inf
     const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
-    int node = alive ? 0 : -1;
-    // a traversal meets each of the 2n-1 nodes at most once: the budget and the index check make a
-    // damaged hierarchy end the search instead of hanging or faulting the GPU
-    const unsigned n_nodes = 2u * (unsigned)ntri - 1u;
-    for (unsigned budget = n_nodes + 1u; budget != 0u && __ballot(node >= 0) != 0ull; --budget) {
-        if ((unsigned)node < n_nodes) {
-            const float4 a = *reinterpret_cast<const float4*>(&nodes[node]);      // bmin.xyz, link
-            const float4 b = *(reinterpret_cast<const float4*>(&nodes[node]) + 1);  // bmax.xyz, miss
-            const float t1x = (a.x - o.x) * ix, t2x = (b.x - o.x) * ix;
-            const float t1y = (a.y - o.y) * iy, t2y = (b.y - o.y) * iy;
-            const float t1z = (a.z - o.z) * iz, t2z = (b.z - o.z) * iz;
-            const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
-            const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-            // a NaN ray or box fails these and the subtree is skipped: nothing in it could be accepted
-            // (a NaN in o or d makes every t NaN; NaN boxes do not exist, non-finite triangles get empty ones)
-            const bool hit = (tnear <= tfar) & (tfar >= 0.0f) & (tnear <= tmax);
-            const unsigned link = __float_as_uint(a.w);
-            int next = __float_as_int(b.w);
-            if (hit) {
-                if (link & 0x80000000u) {
-                    const int i = (int)(link & 0x7fffffffu);
-                    const PtTriRec r = pt_fetch_rec<false>(tris, i);
-                    pt_tri_exact_unordered<DET_BOUNDED>(r, i, o, d, tmax, hu, hv, hidx);
-                } else {
-                    next = (int)link;
-                }
+    unsigned stack[PT_BVH_STACK];
+    int sp = 0;
+    const unsigned n_nodes = (unsigned)ntri - 1u;
+    unsigned node = alive ? 0u : 0xffffffffu;  // 0xffffffff = this lane is done
+    // every internal node is entered at most once: the budget and the index check make a damaged
+    // hierarchy end the search instead of hanging or faulting the GPU
+    for (unsigned budget = n_nodes + 1u; budget != 0u && __ballot(node != 0xffffffffu) != 0ull; --budget) {
+        ++c_iters;
+        if (node < n_nodes) {
+            ++c_nodes;
+            const float4* q = reinterpret_cast<const float4*>(&nodes[node]);
+            const float4 lmin = q[0], lmax = q[1], rmin = q[2], rmax = q[3];
+            const unsigned link_l = __float_as_uint(lmin.w), link_r = __float_as_uint(lmax.w);
+            float tl, tr;
+            bool hit_l = pt_slab(lmin, lmax, o, ix, iy, iz, tmax, tl);
+            if (hit_l && (link_l & 0x80000000u)) {
+                const int i = (int)(link_l & 0x7fffffffu);
+                pt_tri_exact_unordered<DET_BOUNDED>(pt_fetch_rec<false>(tris, i), i, o, d, tmax, hu, hv, hidx);
+                hit_l = false;
+                ++c_leaves;
             }
-            node = next;
+            bool hit_r = pt_slab(rmin, rmax, o, ix, iy, iz, tmax, tr);  // after the left leaf: tmax may have shrunk
+            if (hit_r && (link_r & 0x80000000u)) {
+                const int i = (int)(link_r & 0x7fffffffu);
+                pt_tri_exact_unordered<DET_BOUNDED>(pt_fetch_rec<false>(tris, i), i, o, d, tmax, hu, hv, hidx);
+                hit_r = false;
+                ++c_leaves;
+            }
+            if (hit_l & hit_r) {
+                const bool left_first = tl <= tr;
+                if (sp < PT_BVH_STACK) stack[sp++] = left_first ? link_r : link_l;
+                node = left_first ? link_l : link_r;
+            } else if (hit_l) {
+                node = link_l;
+            } else if (hit_r) {
+                node = link_r;
+            } else {
+                node = sp > 0 ? stack[--sp] : 0xffffffffu;
+            }
         } else {
-            node = -1;
+            node = 0xffffffffu;
         }
     }
+#if PT_BVH_STATS
+    if (bstat && alive) {
+        atomicAdd(&bstat[0], (unsigned long long)c_nodes);
+        atomicAdd(&bstat[1], (unsigned long long)c_leaves);
+        atomicAdd(&bstat[2], (unsigned long long)c_iters);
+        atomicAdd(&bstat[3], 1ull);
+    }
+#else
+    (void)c_nodes; (void)c_leaves; (void)c_iters;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1006,8 +1048,7 @@ template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 // 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
 // (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
 // makes hipcc keep 94 SGPRs (2 spilled to VGPR lanes): 60.9 -> 59.8 ms.
-__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
-void pt_trace_kernel(const PtTraceParams P)
+PTK_DEV void pt_trace_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
     pt_const_f32p T = (pt_const_f32p)(const float*)P.tris;
@@ -1051,7 +1092,7 @@ void pt_trace_kernel(const PtTraceParams P)
 #if PT_TWO_PASS
         unsigned p2steps = 0;
         if (QUADS == PT_ACCEL_BVH)
-            pt_intersect_bvh<DET_BOUNDED>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx);
+            pt_intersect_bvh<DET_BOUNDED>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.stats ? P.stats + 2 : nullptr);
         else
             p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
@@ -1111,6 +1152,22 @@ void pt_trace_kernel(const PtTraceParams P)
     }
 #endif
     pt_flush_counters(P, lane, n_rays, n_samples);
+}
+
+template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
+__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
+void pt_trace_kernel(const PtTraceParams P)
+{
+    pt_trace_body<DET_BOUNDED, LDS_TABLE, QUADS>(P);
+}
+
+// the LBVH search keeps a traversal stack and two boxes live: it gets the registers it asks for
+// (5 waves per SIMD) instead of the brute-force kernel's 7-wave diet
+template <bool DET_BOUNDED>
+__global__ __launch_bounds__(PT_TRACE_THREADS)
+void pt_trace_bvh_kernel(const PtTraceParams P)
+{
+    pt_trace_body<DET_BOUNDED, false, PT_ACCEL_BVH>(P);
 }
 
 // ---- variant 2: rays regrouped by direction octant once per bounce ------------------------------
@@ -1401,8 +1458,8 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
 {
     if (bvh && !sorted) {
         const size_t lds = ptk_trace_lds_bytes(PT_LDS_TRI_MAX + 1);  // camera slots only
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, PT_ACCEL_BVH>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, false, PT_ACCEL_BVH>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (det_bounded) hipLaunchKernelGGL(pt_trace_bvh_kernel<true>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL(pt_trace_bvh_kernel<false>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         return hipGetLastError();
     }
     if (sorted) {
