@@ -281,6 +281,15 @@ def _variant_scene(kind):
             tris[f][1::2, :3] += np.array([0.25, -0.125, 0.5], np.float32)
     elif kind == "quads_nan_second":  # a NaN in the second triangle's e1 only: the pair structure survives
         tris["p2"][9, 1] = np.nan
+    elif kind == "quads_17":        # an odd number of quads: the packed filter's last table entry is half padding
+        tris = tris[:34].copy()
+    elif kind == "quads_2":         # one pair of quads only
+        tris = tris[4:8].copy()
+    elif kind == "quads_72tri":     # three 32-triangle chunks: the box plus a shrunk copy of itself inside it
+        inner = tris.copy()
+        for f in ("p1", "p2", "p3"):
+            inner[f][:, :3] = inner[f][:, :3] * np.float32(0.4) + np.array([0.3, 1.2, -1.9], np.float32)
+        tris = np.concatenate([tris, inner])
     elif kind == "quads_far":       # scene far from the eye relative to its size: large radius, small triangles
         for f in ("p1", "p2", "p3"):
             tris[f][:, :3] = tris[f][:, :3] * np.float32(4.0) + np.array([0.0, -8.25, -160.0], np.float32)
@@ -288,7 +297,8 @@ def _variant_scene(kind):
 
 
 @pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate",
-                                  "quads_skewed", "quads_tiny", "quads_detached", "quads_nan_second", "quads_far"])
+                                  "quads_skewed", "quads_tiny", "quads_detached", "quads_nan_second", "quads_far",
+                                  "quads_17", "quads_2", "quads_72tri"])
 @pytest.mark.parametrize("quad_filter", [0, 1, 2, 3])
 def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
     """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows, 1 = none, 2 = pairs, 3 = shared u."""
