@@ -685,44 +685,52 @@ PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepT
     unsigned stack[PT_BVH_STACK];
     int sp = 0;
     const unsigned n_nodes = (unsigned)ntri - 1u;
-    unsigned node = alive ? 0u : 0xffffffffu;  // 0xffffffff = this lane is done
-    // every internal node is entered at most once: the budget and the index check make a damaged
-    // hierarchy end the search instead of hanging or faulting the GPU
-    for (unsigned budget = n_nodes + 1u; budget != 0u && __ballot(node != 0xffffffffu) != 0ull; --budget) {
+    const unsigned DONE = 0x7fffffffu;         // (an internal-node link this large cannot exist)
+    unsigned cur = alive ? 0u : DONE;          // a link: internal node index, or 0x80000000 | triangle
+    // One 64-byte fetch per step, whatever the step is: internal nodes and prepared triangle records
+    // are both 64 bytes, so a lane at a leaf and a lane at an internal node issue the same four loads
+    // and the wave waits for memory once per step.  Leaves are not tested where their box is hit: the
+    // link goes the way of any child (next, or onto the stack behind a nearer sibling).
+    // Every link is visited at most once: the budget and the index checks make a damaged hierarchy
+    // end the search instead of hanging or faulting the GPU.
+    for (unsigned budget = 2u * (unsigned)ntri; budget != 0u && __ballot(cur != DONE) != 0ull; --budget) {
         ++c_iters;
-        if (node < n_nodes) {
-            ++c_nodes;
-            const float4* q = reinterpret_cast<const float4*>(&nodes[node]);
-            const float4 lmin = q[0], lmax = q[1], rmin = q[2], rmax = q[3];
-            const unsigned link_l = __float_as_uint(lmin.w), link_r = __float_as_uint(lmax.w);
-            float tl, tr;
-            bool hit_l = pt_slab(lmin, lmax, o, ix, iy, iz, tmax, tl);
-            if (hit_l && (link_l & 0x80000000u)) {
-                const int i = (int)(link_l & 0x7fffffffu);
-                pt_tri_exact_unordered<DET_BOUNDED>(pt_fetch_rec<false>(tris, i), i, o, d, tmax, hu, hv, hidx);
-                hit_l = false;
+        if (cur != DONE) {
+            const bool leaf = (cur & 0x80000000u) != 0u;
+            const unsigned idx = cur & 0x7fffffffu;
+            const bool in_range = leaf ? idx < (unsigned)ntri : idx < n_nodes;
+            const float4* q = leaf ? reinterpret_cast<const float4*>(tris + (in_range ? idx : 0u))
+                                   : reinterpret_cast<const float4*>(nodes + (in_range ? idx : 0u));
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            unsigned next = sp > 0 ? stack[sp - 1] : DONE;  // what a pop would give
+            bool pop = true;
+            if (!in_range) {
+                sp = 0; next = DONE;
+            } else if (leaf) {
                 ++c_leaves;
-            }
-            bool hit_r = pt_slab(rmin, rmax, o, ix, iy, iz, tmax, tr);  // after the left leaf: tmax may have shrunk
-            if (hit_r && (link_r & 0x80000000u)) {
-                const int i = (int)(link_r & 0x7fffffffu);
-                pt_tri_exact_unordered<DET_BOUNDED>(pt_fetch_rec<false>(tris, i), i, o, d, tmax, hu, hv, hidx);
-                hit_r = false;
-                ++c_leaves;
-            }
-            if (hit_l & hit_r) {
-                const bool left_first = tl <= tr;
-                if (sp < PT_BVH_STACK) stack[sp++] = left_first ? link_r : link_l;
-                node = left_first ? link_l : link_r;
-            } else if (hit_l) {
-                node = link_l;
-            } else if (hit_r) {
-                node = link_r;
+                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z ...
+                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
+                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)idx, o, d, tmax, hu, hv, hidx);
             } else {
-                node = sp > 0 ? stack[--sp] : 0xffffffffu;
+                ++c_nodes;
+                const unsigned link_l = __float_as_uint(q0.w), link_r = __float_as_uint(q1.w);
+                float tl, tr;
+                const bool hit_l = pt_slab(q0, q1, o, ix, iy, iz, tmax, tl);
+                const bool hit_r = pt_slab(q2, q3, o, ix, iy, iz, tmax, tr);
+                if (hit_l & hit_r) {
+                    const bool left_first = tl <= tr;
+                    if (sp < PT_BVH_STACK) stack[sp++] = left_first ? link_r : link_l;
+                    next = left_first ? link_l : link_r;
+                    pop = false;
+                } else if (hit_l | hit_r) {
+                    next = hit_l ? link_l : link_r;
+                    pop = false;
+                }
             }
-        } else {
-            node = 0xffffffffu;
+            if (pop && sp > 0) --sp;
+            cur = next;
         }
     }
 #if PT_BVH_STATS
