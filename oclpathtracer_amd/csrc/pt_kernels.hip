@@ -316,10 +316,16 @@ PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
     float4 q0, q1;
     float e2z;
     if (LDS_TABLE) {
-        const int w = i * PT_LDS_TRI_STRIDE;
-        q0 = *reinterpret_cast<const float4*>(&pt_lds_tab[w]);
-        q1 = *reinterpret_cast<const float4*>(&pt_lds_tab[w + 4]);
-        e2z = pt_lds_tab[w + 8];
+        // 32-bit LDS addressing: through the generic pointer hipcc forms the address with a 64-bit
+        // v_mad_u64_u32 per survivor
+        typedef __attribute__((address_space(3))) const float pt_lds_f32;
+        typedef float pt_v4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const pt_v4 pt_lds_f32x4;
+        pt_lds_f32* t = (pt_lds_f32*)pt_lds_tab + __umul24((unsigned)i, (unsigned)PT_LDS_TRI_STRIDE);  // i <= 256
+        const pt_v4 a = *(pt_lds_f32x4*)t, b = *(pt_lds_f32x4*)(t + 4);
+        q0 = make_float4(a.x, a.y, a.z, a.w);
+        q1 = make_float4(b.x, b.y, b.z, b.w);
+        e2z = t[8];
     } else {
         const float* t = reinterpret_cast<const float*>(tris + i);
         q0 = *reinterpret_cast<const float4*>(t);
@@ -608,12 +614,14 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         if (p1_ticks) *p1_ticks += tb - ta;
 #endif
         // every lane tests its next survivor (index 0 and ok = false once it has none left)
-        while (__ballot(m != 0u) != 0ull) {
+        for (pt_lanes more = PT_LANES(m != 0u); more != 0ull; more = PT_LANES(m != 0u)) {
             ++steps;
             const bool valid = m != 0u;
             unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
             asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
-            const int i = valid ? base + n - 32 + (int)lz : base;
+            // (a lane without survivors forms a wild index: harmless for the LDS table -- out-of-range
+            // LDS reads return 0 -- and its result is discarded; the global table needs a real address)
+            const int i = (LDS_TABLE || valid) ? base + n - 32 + (int)lz : base;
             m &= ~(0x80000000u >> (lz & 31u));
             const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
             pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
