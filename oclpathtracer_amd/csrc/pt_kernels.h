@@ -34,7 +34,7 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
-#define PT_TRACE_BATCH 256u    // samples per work-queue grab (one wave)
+#define PT_TRACE_BATCH 256u    // largest number of samples per work-queue grab of a wave (PtTraceParams::batch)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
 #define PT_LDS_TRI_STRIDE 12    // dwords per triangle record in the LDS copy (p1, e1, e2, 3 pad)
 #define PT_LDS_TRI_MAX 256      // scenes up to this many triangles keep the copy (12 KiB per workgroup)
@@ -55,6 +55,7 @@ struct PtTraceParams {
     int32_t stripe_rows, n_ranks, rank;
     uint32_t npix_local;
     uint32_t batches_per_frame, total_batches;
+    uint32_t batch;               // samples per work-queue grab: 64, 128 or 256 (<= PT_TRACE_BATCH)
     float quad_delta1;            // quad mode 2 (pt_quad2_pass1): slack of the shared-u bounds
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads

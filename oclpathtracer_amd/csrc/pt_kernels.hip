@@ -790,8 +790,8 @@ PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, Pt
             unsigned f = b / P.batches_per_frame;
             unsigned bi = b - f * P.batches_per_frame;
             q.frame = f;
-            q.pix = bi * PT_TRACE_BATCH;
-            unsigned e = q.pix + PT_TRACE_BATCH;
+            q.pix = bi * P.batch;
+            unsigned e = q.pix + P.batch;
             q.end = e < P.npix_local ? e : P.npix_local;
             q.row = q.pix / (unsigned)P.width;  // one wave-uniform division per 256 samples
             q.col = q.pix - q.row * (unsigned)P.width;
@@ -997,7 +997,7 @@ struct PtQueueB {
 
 PTK_DEV void pt_camera_batch(const PtTraceParams& P, unsigned lane, const PtQueueB& q, float4* cam)
 {
-    for (unsigned k = 0; k < PT_TRACE_BATCH; k += 64) {
+    for (unsigned k = 0; k < P.batch; k += 64) {
         const unsigned lp = q.base + k + lane;
         if (lp < q.end) {
             const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
@@ -1034,8 +1034,8 @@ PTK_DEV void pt_regenerate_bulk(const PtTraceParams& P, unsigned lane, PtQueueB&
             unsigned f = b / P.batches_per_frame;
             unsigned bi = b - f * P.batches_per_frame;
             q.frame = f;
-            q.pix = q.base = bi * PT_TRACE_BATCH;
-            unsigned e = q.pix + PT_TRACE_BATCH;
+            q.pix = q.base = bi * P.batch;
+            unsigned e = q.pix + P.batch;
             q.end = e < P.npix_local ? e : P.npix_local;
             pt_camera_batch(P, lane, q, cam);
         }

@@ -764,7 +764,16 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     }
     HIP_TRY(hipMemsetAsync(d->counters, 0, (size_t)nchunks * sizeof(unsigned int), d->stream));
 
-    const uint32_t bpf = (npix + PT_TRACE_BATCH - 1) / PT_TRACE_BATCH;
+    // Samples per work-queue grab.  A wave that finds the queue empty idles until the last wave is
+    // done, on average for half a batch: large batches (fewer atomics) when every wave gets many of
+    // them, smaller ones when the launch is short (a rank's share of a multi-GPU render, small images).
+    const uint64_t resident_waves = (uint64_t)d->prop.multiProcessorCount * (uint64_t)d->blocks_per_cu * (PT_TRACE_THREADS / 64);
+    const uint64_t chunk_samples = (uint64_t)npix * (uint64_t)std::min(chunk, rp.frame_count);
+    // (not below 128: at 64 the ONE queue counter takes 4 M atomics per launch of configs[2] and the
+    // L2 atomic unit saturates -- measured +30 % launch time)
+    uint32_t batch = PT_TRACE_BATCH;
+    while (batch > 128u && chunk_samples / batch < 64u * resident_waves) batch >>= 1;
+    const uint32_t bpf = (npix + batch - 1) / batch;
     for (int c = 0; c < nchunks; ++c) {
         int f0 = c * chunk;
         int nf = std::min(chunk, rp.frame_count - f0);
@@ -790,6 +799,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.npix_local = npix;
         tp.batches_per_frame = bpf;
         tp.total_batches = (uint32_t)total_batches;
+        tp.batch = batch;
         tp.quad_delta1 = d->prep_delta1;
         tp.ray_radius = d->prep_ray_radius;
         tp.p1tab = d->p1tab;
