@@ -4,18 +4,22 @@
 // (test/ClKernels/GenerateColors.cl:302-322: one work-item = one pixel = one path, then a
 // read-modify-write of the gamma-encoded running mean) is restructured for CDNA4 as
 //
-//   pt_prep_kernel   once per scene upload: Triangle -> {p1, e1, e2, n, id}
+//   pt_prep_kernel   once per scene upload: Triangle -> {p1, e1, e2, n, id}; for scenes made of
+//                    quads also the slack and the packed table of the pass-1 filter
 //   pt_trace_kernel  persistent waves; every LANE owns one path at a time and, when its path
-//                    ends, immediately starts the next (pixel, frame) sample taken from a
-//                    wave-local range of a global batch queue (ballot + mbcnt compaction), so
-//                    the closest-hit search always runs with a full exec mask.  The search is
-//                    two-pass: pass 1 walks the triangles with a wave-uniform index (records are
+//                    ends, immediately starts the next (pixel, frame) sample of the wave's current
+//                    batch of a global queue (ballot + mbcnt compaction; the batch's camera rays
+//                    are generated 64 wide into LDS when the batch is taken), so the closest-hit
+//                    search always runs with a full exec mask.  The search is two-pass: pass 1
+//                    walks the triangles with a wave-uniform index (per-triangle constants are
 //                    scalar loads consumed as SGPR operands) and keeps, per lane, a bit mask of
-//                    the triangles that MAY pass the cull and u tests (a cheap conservative
-//                    filter, quad pairs sharing one cross product); pass 2 lets every lane run
-//                    the exact reference test on its own ~3 survivors, fetched per lane from an
-//                    LDS copy of the records.  Path radiance goes to rad[frame][pixel].
-//   pt_fold_kernel   per pixel, in ascending frame order, replays the reference's
+//                    the triangles that MAY pass the cull and u tests -- a conservative filter,
+//                    in its strongest form one packed FMA chain deciding four triangles
+//                    (pt_quad3_pass1); pass 2 lets every lane run the exact reference test on its
+//                    own ~3 survivors, fetched per lane from an LDS copy of the records.  Scenes
+//                    of 512 triangles or more walk an LBVH instead (pt_intersect_bvh, pt_bvh.hip).
+//                    Path radiance goes to rad[frame][pixel].
+//   pt_fold_kernel   per pixel channel, in ascending frame order, replays the reference's
 //                    gamma -> mean -> degamma arithmetic (GenerateColors.cl:314-321) over the
 //                    staged radiances: bit-identical to frame-by-frame launches.
 //
@@ -1063,9 +1067,6 @@ PTK_DEV void pt_regenerate_bulk(const PtTraceParams& P, unsigned lane, PtQueueB&
 }
 
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
-// 7 waves per SIMD: the kernel needs 63 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
-// (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
-// makes hipcc keep 94 SGPRs (2 spilled to VGPR lanes): 60.9 -> 59.8 ms.
 PTK_DEV void pt_trace_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
@@ -1172,6 +1173,10 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
+// 7 waves per SIMD: the kernel needs 67 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
+// (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
+// makes hipcc keep 94 SGPRs (a few spilled to VGPR lanes): 60.9 -> 59.8 ms when introduced; 8 waves
+// (64 VGPRs, 78 SGPRs, 10 + 28 spills) is slower again: 38.2 vs 36.8 ms.
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 __global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void pt_trace_kernel(const PtTraceParams P)
