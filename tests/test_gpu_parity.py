@@ -374,3 +374,32 @@ def test_bvh_matches_gpu_brute_force_200k_triangles(device):
             device.setOption(shim.PT_OPT_ACCEL, 0)
     assert_fb_equal(out[2][0], out[1][0], "bvh vs brute force, 200k triangles")
     assert out[2][1]["rays"] == out[1][1]["rays"]
+
+
+def test_gpu_render_matches_reference_jpg(device, cornell):
+    """The HIP path at the reference's own settings (512x512; 4000 frames of its 10000-frame loop)
+    through the device output stage against the 8x8-pixel block means of the reference's rendered image
+    (tests/golden/reference_jpg_blocks_64x64.npy, from FinalRendered_Specular.jpg): within Monte-Carlo +
+    JPEG noise.  The statistical pin of the whole path against the real OpenCL output."""
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+    import ctypes
+
+    ref = np.load(os.path.join(GOLDEN, "reference_jpg_blocks_64x64.npy")).astype(np.float64)
+    tris, mats = cornell
+    W, frames, G = 512, 4000, 64
+    r = Renderer(device, tris, mats, W, W)
+    try:
+        r.render(frames)
+        fb = r.read()
+    finally:
+        r.release()
+    img = scene.f2c(fb[:, :3]).reshape(W, W, 3).astype(np.float64)
+    blocks = img.reshape(G, W // G, G, W // G, 3).mean(axis=(1, 3))
+    diff = np.abs(blocks - ref)
+    corr = np.corrcoef(blocks.ravel(), ref.ravel())[0, 1]
+    print("gpu vs reference JPG, 64x64 blocks: mean |diff| %.2f max %.1f corr %.5f" % (diff.mean(), diff.max(), corr))
+    # measured: mean |diff| 0.74 of 255, worst block 8.6, correlation 0.99995
+    assert diff.mean() < 1.5, diff.mean()
+    assert diff.max() < 16.0, diff.max()
+    assert corr > 0.9998, corr
