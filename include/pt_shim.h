@@ -149,6 +149,12 @@ void* pt_buffer_map(pt_buffer_t buf, size_t bytes, int blocking);
  * Copies the staging range back to the device (asynchronously) and releases it. */
 int pt_buffer_unmap(pt_buffer_t buf, void* host_ptr);
 
+/* Page-locked host memory, so that pt_buffer_read / pt_buffer_write into it are truly asynchronous
+ * (the progressive driver's double-buffered readback).  No Adl counterpart: the
+ * reference only has the driver-owned mapping of getHostPtr. */
+int pt_host_alloc(size_t bytes, void** out);
+int pt_host_free(void* host_ptr);
+
 /* ---- events (SyncObject : Adl/AdlKernel.h:45-54, AdlCL.inl:452-478) ------------------- */
 int pt_event_create(pt_device_t dev, pt_event_t* out);
 int pt_event_destroy(pt_event_t ev);

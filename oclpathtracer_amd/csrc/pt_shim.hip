@@ -488,6 +488,23 @@ extern "C" int pt_buffer_copy(pt_buffer_t dst, pt_buffer_t src, size_t bytes, si
     return event_end(d, ev);
 }
 
+extern "C" int pt_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (g_init_count <= 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not succeeded");
+    hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(PT_ERR_OOM, "pinned host allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e)); }
+    return PT_OK;
+}
+
+extern "C" int pt_host_free(void* host_ptr)
+{
+    if (!host_ptr) return PT_OK;
+    HIP_TRY(hipHostFree(host_ptr));
+    return PT_OK;
+}
+
 extern "C" void* pt_buffer_map(pt_buffer_t b, size_t bytes, int blocking)
 {
     if (!b) { fail(PT_ERR_INVALID, "null buffer handle"); return nullptr; }

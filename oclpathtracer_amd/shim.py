@@ -81,6 +81,8 @@ SIGNATURES = {
     "pt_buffer_copy": (_c.c_int, [_H, _H, _c.c_size_t, _c.c_size_t, _c.c_size_t, _H]),
     "pt_buffer_map": (_c.c_void_p, [_H, _c.c_size_t, _c.c_int]),
     "pt_buffer_unmap": (_c.c_int, [_H, _c.c_void_p]),
+    "pt_host_alloc": (_c.c_int, [_c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "pt_host_free": (_c.c_int, [_c.c_void_p]),
     "pt_event_create": (_c.c_int, [_H, _c.POINTER(_H)]),
     "pt_event_destroy": (_c.c_int, [_H]),
     "pt_event_wait": (_c.c_int, [_H]),
