@@ -1441,7 +1441,7 @@ __global__ void pt_math_kernel(const float* __restrict__ in, float* __restrict__
     if (i >= n) return;
     float x = in[i];
     float s = 0.0f, c = 0.0f;
-    if (x >= 0.0f && x <= 8.0f) pt_sincos(x, s, c);  // PTSPEC defines sin/cos for phi in [0, 2 pi]
+    if (x >= 0.0f && x <= 1.0e6f) pt_sincos(x, s, c);  // PTSPEC defines sin/cos for phi >= 0 (binary32 path on [0, 2 pi])
     out[4 * i + 0] = s;
     out[4 * i + 1] = c;
     out[4 * i + 2] = pt_pow(x, PTK_GAMMA, pt_pow_logc_tab, pt_pow_logl_tab, pt_pow_exp2_tab);

@@ -210,6 +210,9 @@ def test_device_transcendentals_match_oracle_bitwise(device, oracle):
     n = 1 << 22
     phi = (np.float32(6.28318530718) * rng.random(n, dtype=np.float32)).astype(np.float32)
     phi[:4] = [0.0, np.float32(6.28318530718), np.float32(3.14159274), np.float32(1.57079637)]
+    # arguments outside [0, 2 pi] take PTSPEC's binary64 evaluation: exercise it too
+    phi[4:1028] = rng.uniform(6.2832, 300.0, 1024).astype(np.float32)
+    phi[1028:1030] = [np.float32(6.283186), np.float32(6.2831864)]  # the binary32 path's last angle, the first beyond it
     xs = np.concatenate([
         (10.0 ** rng.uniform(-44, 38, n // 2)).astype(np.float32),
         rng.random(n // 2 - 16, dtype=np.float32) * np.float32(100.0),
