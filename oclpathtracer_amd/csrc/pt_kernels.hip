@@ -508,11 +508,11 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
     // mode 2: the assumptions of pt_quad2_pass1's error bound, checked for THIS ray
     bool tame = true;
-    PtRay3 r3;
+    PtRay3 r3v;
     if (QUADS == 3 && DET_BOUNDED) {
         const f3 oc = mk3(o.x - PT_EYE_X, o.y - PT_EYE_Y, o.z - PT_EYE_Z);
         const f3 M = cross3(oc, d);
-        r3.dxy = pt_f2{ d.x, d.y }; r3.dzMx = pt_f2{ d.z, M.x }; r3.Myz = pt_f2{ M.y, M.z };
+        r3v.dxy = pt_f2{ d.x, d.y }; r3v.dzMx = pt_f2{ d.z, M.x }; r3v.Myz = pt_f2{ M.y, M.z };
     }
     if (QUADS >= 2 && DET_BOUNDED) {
         float dd = pt_fma(d.z, d.z, pt_fma(d.y, d.y, d.x * d.x));
@@ -527,7 +527,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             pt_const_f32p tp = p1tab + PT_P1_STRIDE * (base >> 2);  // base is a multiple of 32: 4 triangles per quad pair
             for (int j = 0; j < n; j += 4, tp += PT_P1_STRIDE) {
                 pt_f2 un, th;
-                pt_quad3_pass1(tp, r3, un, th);
+                pt_quad3_pass1(tp, r3v, un, th);
                 {
                     const pt_lanes in = PT_LANES(!(__builtin_fabsf(un.x) > th.x));
                     m = pt_push_flag(pt_push_flag(m, in & PT_LANES(!(un.x < p1_lo))), in & PT_LANES(!(un.x > p1_hi)));
@@ -606,6 +606,28 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
                     float q1 = e1 / delta1, q3 = (e2 * 1.000001f + e1) / delta3;
                     r1 = q1 > r1 ? q1 : r1;
                     r3 = q3 > r3 ? q3 : r3;
+                }
+                if (QUADS == 3) {
+                    // mode 3 instead: how far its own roundings are from the reference's floats, relative to
+                    // the slack budgeted for that: |un_here - un_ref| / deltaP and |det_here c - det_ref c| / deltaD
+                    r1 = r3 = 0.0f;
+                    const float deltaP = -p1_lo, deltaD = deltaP * (128.0f / 192.0f);
+                    for (int jj = 0; jj + 1 < n; jj += 4) {
+                        pt_f2 unp, thp;
+                        pt_const_f32p tq = p1tab + PT_P1_STRIDE * ((base + jj) >> 2);
+                        pt_quad3_pass1(tq, r3v, unp, thp);
+                        for (int h = 0; h < 2 && jj + 2 * h + 1 < n; ++h) {
+                            const PtTriRec a = pt_load_tri(T, base + jj + 2 * h);
+                            float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y)), pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z)), pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
+                            float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
+                            float unA = pt_fma(o.z - a.p1z, pvz, pt_fma(o.y - a.p1y, pvy, (o.x - a.p1x) * pvx));
+                            const float dhi = tq[18 + h];
+                            const float q1 = __builtin_fabsf((h ? unp.y : unp.x) - unA) / deltaP;
+                            const float q3 = __builtin_fabsf(((h ? thp.y : thp.x) - dhi) - detA * 1.000002f) / deltaD;
+                            r1 = q1 > r1 ? q1 : r1;
+                            r3 = q3 > r3 ? q3 : r3;
+                        }
+                    }
                 }
                 atomicMax(&vstat[4], (unsigned long long)__float_as_uint(r1));
                 atomicMax(&vstat[5], (unsigned long long)__float_as_uint(r3));

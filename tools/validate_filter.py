@@ -47,6 +47,9 @@ if out[6] or out[7]:  # shared-u filter active: headroom of its error bounds (mu
     r1, r3 = (float(np.array([x], np.uint64).astype(np.uint32).view(np.float32)[0]) for x in out[6:8])
     # r1 is rounding only (large headroom expected); r3 includes the Cauchy-Schwarz bound
     # |w.pvec| <= |w||e2| of a non-parallelogram pair, which rays do attain: it approaches 1 by design
-    print("         shared-u bounds: max |un'+unA|/delta1 = %.4f, max (|det'-detA| c + |un'+unA|)/delta3 = %.4f" % (r1, r3))
+    if quad_filter in (0, 4):  # packed Pluecker form: its own roundings against the reference's floats (both rounding only)
+        print("         packed filter: max |un_here-un_ref|/deltaP = %.4f, max |det_here-det_ref| c/deltaD = %.4f" % (r1, r3))
+    else:
+        print("         shared-u bounds: max |un'+unA|/delta1 = %.4f, max (|det'-detA| c + |un'+unA|)/delta3 = %.4f" % (r1, r3))
     viol += int(r1 > 1.0 or r3 > 1.0)
 sys.exit(1 if viol else 0)
