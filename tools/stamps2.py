@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: s_memtime shares of the sub-phases of pt_shade (needs the PT_STAMPS=2 build:
-hipcc ... -DPT_STAMPS=2 -o oclpathtracer_amd/libptshim_stamps2.so).  usage: PT_SHIM_LIB=... python tools/stamps2.py"""
+make -C oclpathtracer_amd/csrc ../libptshim_stamps2.so).  usage: PT_SHIM_LIB=... python tools/stamps2.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
