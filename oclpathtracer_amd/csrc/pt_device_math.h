@@ -207,13 +207,15 @@ PTK_DEV float pt_pow(float x, float y, const double* logc, const double* logl, c
     int idx = (int)(bits >> 45) & 127;
     bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
     double m = __longlong_as_double((long long)bits);
+    // (coefficients pinned to SGPR pairs, pt_k64: from VGPR pairs hipcc forms every Horner step as
+    // v_mov_b64 + v_fmac_f64 instead of one v_fma_f64 -- 10 extra instructions per pow)
     double r = pt_fmad(m, logc[idx], -1.0);
-    double p = PTK_LOG2_A6;
-    p = pt_fmad(p, r, PTK_LOG2_A5);
-    p = pt_fmad(p, r, PTK_LOG2_A4);
-    p = pt_fmad(p, r, PTK_LOG2_A3);
-    p = pt_fmad(p, r, PTK_LOG2_A2);
-    p = pt_fmad(p, r, PTK_LOG2_A1);
+    double p = pt_k64(PTK_LOG2_A6);
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A5));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A4));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A3));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A2));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A1));
     double l = pt_fmad(r, p, (double)e + logl[idx]);
     double t = (double)y * l;
     if (t >= 130.0) return __builtin_inff();
@@ -222,11 +224,11 @@ PTK_DEV float pt_pow(float x, float y, const double* logc, const double* logl, c
     double f = pt_fmad(-(double)ki, 0x1p-7, t);
     int j = ki & 127;
     int q = (ki - j) >> 7;
-    double g = PTK_EXP2_B5;
-    g = pt_fmad(g, f, PTK_EXP2_B4);
-    g = pt_fmad(g, f, PTK_EXP2_B3);
-    g = pt_fmad(g, f, PTK_EXP2_B2);
-    g = pt_fmad(g, f, PTK_EXP2_B1);
+    double g = pt_k64(PTK_EXP2_B5);
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B4));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B3));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B2));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B1));
     double w = f * g;
     double T = exp2t[j];
     double res = pt_fmad(T, w, T);
