@@ -461,3 +461,56 @@ def test_random_quad_scenes_match_oracle(device, oracle, seed):
             device.setOption(shim.PT_OPT_ACCEL, 0)
         assert_fb_equal(got, want, "random quads seed %d accel %d (%d triangles)" % (seed, accel, len(tris)))
         assert gst["rays"] == st["rays"]
+
+
+def test_configs3_one_rank_of_eight_sampled_pixels(device, cornell, oracle):
+    """BASELINE configs[3] geometry: 2048x2048 dealt to 8 ranks in 16-row stripes; rank 5's share
+    (256 rows, 524 288 pixels) rendered for 8 frames, runs of its pixels recomputed by the oracle
+    from their GLOBAL ids (seed parity across the split, GenerateColors.cl:305-308)."""
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    W = H = 2048
+    frames, n_ranks, rank, stripe = 8, 8, 5, 16
+    r = Renderer(device, tris, mats, W, H, n_ranks=n_ranks, rank=rank, stripe_rows=stripe)
+    try:
+        r.render(frames)
+        got = r.read()
+        rows = r.global_rows()
+    finally:
+        r.release()
+    assert len(rows) == H // n_ranks and got.shape == (len(rows) * W, 4)
+    assert np.all(got[:, 3] == 1.0)
+    rng = np.random.default_rng(3)
+    fb = np.zeros((H * W, 4), np.float32)
+    for lr in rng.integers(0, len(rows), 12):
+        x0 = int(rng.integers(0, W - 64))
+        g0 = int(rows[lr]) * W + x0
+        oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=g0, gid_count=64)
+        assert_fb_equal(got[lr * W + x0: lr * W + x0 + 64], fb[g0: g0 + 64], "C4 rank %d local row %d" % (rank, lr))
+
+
+def test_configs4_million_triangle_soup(device, oracle):
+    """BASELINE configs[4] scene: the 10^6-triangle soup.  The LBVH render (the default from 512
+    triangles on) against the brute-force kernel (PT_OPT_ACCEL = 1) on a 96x64 image, and both against
+    the CPU oracle on the first 64 pixels: identical bits."""
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = scene.make_soup(1_000_000)
+    W, H, frames = 96, 64, 2
+    out = {}
+    for accel in (0, 1):
+        device.setOption(shim.PT_OPT_ACCEL, accel)
+        r = Renderer(device, tris, mats, W, H, want_stats=True)
+        try:
+            r.render(frames)
+            out[accel] = (r.read(), r.read_stats())
+        finally:
+            r.release()
+            device.setOption(shim.PT_OPT_ACCEL, 0)
+    assert_fb_equal(out[0][0], out[1][0], "1M-triangle soup, LBVH vs brute force")
+    assert out[0][1]["rays"] == out[1][1]["rays"]
+    fb = np.zeros((W * H, 4), np.float32)
+    oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=0, gid_count=64)
+    assert_fb_equal(out[0][0][:64], fb[:64], "1M-triangle soup, LBVH vs oracle")
