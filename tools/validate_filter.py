@@ -32,6 +32,14 @@ elif kind == "tiny":          # the box shrunk around the eye: margins near thei
     eye = np.array([0.0, 2.75, 4.0], np.float32)
     for f in ("p1", "p2", "p3"):
         t[f][:, :3] = (t[f][:, :3] - eye) * np.float32(0.01) + eye + np.array([0.0, 0.0, -0.05], np.float32)
+elif kind.startswith("random:"):  # the fuzz scenes of tests/test_gpu_parity.py::_random_quad_scene
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    spec = importlib.util.spec_from_file_location("tgp", os.path.join(root, "tests", "test_gpu_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    t, m = mod._random_quad_scene(int(kind.split(":")[1]))
 assert adl.init()
 dev = adl.DeviceUtils.allocate()
 dev.setOption(shim.PT_OPT_QUAD_FILTER, quad_filter)
