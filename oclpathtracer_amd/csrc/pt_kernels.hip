@@ -354,7 +354,10 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
     float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
     float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
     float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    bool ok = valid & !(det < 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109 (pass 1 kept a superset)
+    // :100, :109 (pass 1 kept a superset).  `u > 1.0f` of :109 needs no compare of its own here: with
+    // v >= 0 (or -0) round-to-nearest gives u + v >= u > 1, which :117 rejects below; with v NaN the
+    // same NaN reaches t (through qvec or inv_det) and :125 rejects.  The accepted set is unchanged.
+    bool ok = valid & !(det < 1e-8f) & !(u < 0.0f);
     float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
     float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
     float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
