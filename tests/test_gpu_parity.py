@@ -514,3 +514,35 @@ def test_configs4_million_triangle_soup(device, oracle):
     fb = np.zeros((W * H, 4), np.float32)
     oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=0, gid_count=64)
     assert_fb_equal(out[0][0][:64], fb[:64], "1M-triangle soup, LBVH vs oracle")
+
+
+def test_bvh_exact_ties_go_to_the_lowest_index(device, oracle, cornell):
+    """Every Cornell triangle 17 more times, shuffled, behind the originals (648 triangles: LBVH by
+    default): each hit is an exact tie in t between 18 copies, which the reference's ascending loop with
+    its strict `t < tmax` (GenerateColors.cl:125,145-151) gives to the lowest index.  The copies carry
+    OTHER materials than the originals, so a traversal that resolved ties by visiting order would
+    change the image."""
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    rng = np.random.default_rng(5)
+    copies = np.concatenate([tris[rng.permutation(len(tris))] for _ in range(17)])
+    copies["id"] = (copies["id"] + 7) % len(mats)       # a copy would shade differently
+    big = np.concatenate([tris, copies])
+    W, H, frames = 64, 48, 3
+    want, st = oracle.render(big, mats, W, H, frames, want_stats=True)
+    base = oracle.render(tris, mats, W, H, frames)
+    assert np.array_equal(want.view(np.uint32), base.view(np.uint32))  # the oracle itself: copies never win
+    for accel in (0, 1):
+        device.setOption(shim.PT_OPT_ACCEL, accel)
+        r = Renderer(device, big, mats, W, H, want_stats=True)
+        try:
+            r.render(frames)
+            got = r.read()
+            gst = r.read_stats()
+        finally:
+            r.release()
+            device.setOption(shim.PT_OPT_ACCEL, 0)
+        assert_fb_equal(got, want, "tie scene, accel %d" % accel)
+        assert gst["rays"] == st["rays"]
