@@ -546,3 +546,36 @@ def test_bvh_exact_ties_go_to_the_lowest_index(device, oracle, cornell):
             device.setOption(shim.PT_OPT_ACCEL, 0)
         assert_fb_equal(got, want, "tie scene, accel %d" % accel)
         assert gst["rays"] == st["rays"]
+
+
+@pytest.mark.parametrize("depth", [1, 3, 40])
+def test_depth_caps_outside_the_baseline_configs(device, cornell, oracle, depth):
+    """max_bounces is a runtime parameter of the fused entry point (the reference compiles BOUNCES = 16,
+    GenerateColors.cl:5): one bounce, three, and more than the reference's cap."""
+    tris, mats = cornell
+    W, H, frames = 64, 40, 4
+    want = oracle.render(tris, mats, W, H, frames, max_bounces=depth)
+    got = _render_gpu(device, tris, mats, W, H, frames, depth=depth)
+    assert_fb_equal(got.reshape(-1, 4), want, "depth %d" % depth)
+
+
+def test_empty_scene_and_zero_frames(device, cornell, oracle):
+    """No triangles at all: every path leaves on its first ray (GenerateColors.cl:233-237).  And a
+    render of zero frames is a no-op that leaves the framebuffer alone."""
+    from oclpathtracer_amd import scene
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    none = np.zeros(0, scene.TRIANGLE_DTYPE)
+    W, H, frames = 48, 32, 3
+    want = oracle.render(none, mats, W, H, frames)
+    r = Renderer(device, none, mats, W, H)
+    try:
+        r.render(frames)
+        got = r.read()
+        r.render(0)
+        again = r.read()
+    finally:
+        r.release()
+    assert_fb_equal(got, want, "empty scene")
+    assert_fb_equal(again, got, "zero frames")
