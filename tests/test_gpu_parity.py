@@ -579,3 +579,22 @@ def test_empty_scene_and_zero_frames(device, cornell, oracle):
         r.release()
     assert_fb_equal(got, want, "empty scene")
     assert_fb_equal(again, got, "zero frames")
+
+
+def test_stripes_with_the_lbvh(device, oracle):
+    """configs[4] runs the soup on 8 ranks: image stripes and the LBVH together (every rank builds its
+    own hierarchy of the replicated scene).  Rank 1 of 4, 8-row stripes, 3000 triangles."""
+    from oclpathtracer_amd import scene
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = scene.make_soup(3000)
+    W, H, frames = 96, 80, 2
+    want = oracle.render(tris, mats, W, H, frames).reshape(H, W, 4)
+    r = Renderer(device, tris, mats, W, H, n_ranks=4, rank=1, stripe_rows=8)
+    try:
+        r.render(frames)
+        got = r.read().reshape(-1, W, 4)
+        rows = r.global_rows()
+    finally:
+        r.release()
+    assert_fb_equal(got.reshape(-1, 4), want[rows].reshape(-1, 4), "stripes + LBVH")
