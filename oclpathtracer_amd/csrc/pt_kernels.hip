@@ -1120,6 +1120,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 #endif
 #if PT_STAMPS == 2
     unsigned long long c_sub[6] = { 0, 0, 0, 0, 0, 0 };
+    (void)c_regen; (void)c_loop; (void)c_shade; (void)c_iters; (void)c_steps;  // this build reports the sub-phases instead
 #endif
 
     for (;;) {
