@@ -9,10 +9,17 @@ The image is fixed as N grows: "scaling": "strong".
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT a torch.distributed launcher (no RANK in the environment) and with --gpus N > 1,
+this process starts the N ranks itself -- N fresh interpreters, created before torch or the HIP
+runtime is loaded here -- relays rank 0's JSON line and exits with the worst rank's code.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (pt_trace_kernel, timed with
 HIP events on its own stream inside the timed region); `cpu_baseline` times the CPU oracle
 ("port": this repo's restatement of the reference kernel -- the reference has no CPU executor)
-on a bounded sample of the same workload on rank 0's host cores, at N=1 only.
+on a bounded sample of the same workload on rank 0's host cores, at N=1 only.  `extra.configs`
+(N=1 only) carries the other single-GPU BASELINE configurations, timed in the same process
+after the headline region: configs[1] (512^2 x 64 spp, depth 2) and configs[4]'s scene
+(10^6-triangle soup, 1024^2 x 256 spp, through the LBVH).
 """
 from __future__ import annotations
 
@@ -20,6 +27,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +43,10 @@ F_GEN, F_ACC = 60.0, 36.0
 F_TRI = {"cull": 20.0, "rej_u": 30.0, "rej_v": 46.0, "reach_t": 52.0}
 F_ACCEPT, F_SHADE_DIFFUSE, F_SHADE_SPECULAR = 33.0, 120.0, 160.0
 BYTES_PER_SAMPLE = 32.0         # 16 B read + 16 B write of one float4 pixel (GenerateColors.cl:314-321)
+# LBVH search (configs[4]): per node entered, two slab tests (6 sub, 6 mul, 12 min/max, 3 compares = 27 flop
+# each) + ordering; per triangle tested the reference's full test (52, reach_t) -- DESIGN.md S4
+F_BVH_NODE, F_BVH_TRI = 56.0, 52.0
+B_BVH_NODE, B_BVH_TRI = 64.0, 64.0  # one 64-byte record fetched per node entered / triangle tested
 
 
 def pmc_traffic():
@@ -106,23 +119,106 @@ def cpu_baseline(tris, mats, depth, target_seconds=12.0):
     }, st
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150, help="timed renders (default: a timed region of about 5 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="trace kernel: 0 library default, 1 lane-regenerating, 2 octant-sorted")
-    ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 2 pairs, 3 shared u, 4 packed")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] / configs[4] legs of extra.configs")
+    ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 4 packed")
     ap.add_argument("--accel", type=int, default=0, help="PT_OPT_ACCEL: 0 auto (LBVH from 512 triangles), 1 brute force, 2 LBVH")
     ap.add_argument("--soup", type=int, default=0, help="render the synthetic N-triangle soup of BASELINE configs[4] (Cornell box + "
-                    "N-36 small triangles) instead of cornellbox.bin; exploration only: no roofline / cpu_baseline objects")
-    args = ap.parse_args()
+                    "N-36 small triangles) instead of cornellbox.bin (no cpu_baseline: the oracle is O(N) per ray)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > visible GPUs: ranks share devices (rank %% device_count) and gather over gloo through the host. "
+                         "Exercises the N-rank code path on a smaller box; the line says so and is no scaling measurement")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# self-launch: N fresh interpreters, started before this process has loaded torch or HIP
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %d" % rc for rc in bad))
+        return max(abs(c) for _, c in bad) or 1
+    return 0
+
+
+def time_render(img, fence, steps, warmup, spp, depth):
+    """W warm-up renders, then K timed ones bracketed by fence(); returns seconds."""
+    for _ in range(warmup):
+        img.render(spp, frame_begin=0, max_bounces=depth)
+        img.gather()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img.render(spp, frame_begin=0, max_bounces=depth)
+        img.gather()
+    fence()
+    return time.perf_counter() - t0
+
+
+def bvh_tallies(dev, lib, shim, tris, mats, W, H, depth):
+    """Per-ray averages of the LBVH search (nodes entered, triangles tested) from a short tallied render
+    (PT_OPT_BVH_TALLY: the same kernel with its work counters switched on; never the timed one)."""
+    from oclpathtracer_amd.render import Renderer
+
+    dev.setOption(shim.PT_OPT_BVH_TALLY, 1)
+    try:
+        r = Renderer(dev, tris, mats, W, H, want_stats=True)
+        r.render(2, max_bounces=depth)
+        st = r.read_stats_raw()
+        r.release()
+    finally:
+        dev.setOption(shim.PT_OPT_BVH_TALLY, 0)
+    rays = max(int(st[shim.PT_STAT_RAYS]), 1)
+    return {"nodes_per_ray": int(st[shim.PT_STAT_BVH_NODES]) / rays, "tris_per_ray": int(st[shim.PT_STAT_BVH_TRIS]) / rays,
+            "wave_iterations_per_ray_wave": int(st[shim.PT_STAT_BVH_ITERS]) / max(int(st[shim.PT_STAT_BVH_WAVES]), 1)}
+
+
+def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):
+    flops = samples_per_launch * (F_GEN + F_ACC) + rays_per_launch * (
+        tally["nodes_per_ray"] * F_BVH_NODE + tally["tris_per_ray"] * F_BVH_TRI + F_SHADE_DIFFUSE)
+    bytes_ = rays_per_launch * (tally["nodes_per_ray"] * B_BVH_NODE + tally["tris_per_ray"] * B_BVH_TRI) + samples_per_launch * 16.0
+    tfl = flops / (avg_ms * 1e-3) / 1e12
+    gbs = bytes_ / (avg_ms * 1e-3) / 1e9
+    return ({"bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
+             "traffic": None, "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+             "flops_basis": "per ray: %.1f nodes entered x %.0f + %.2f triangles tested x %.0f + %.0f shading (tallied render, PT_OPT_BVH_TALLY)"
+                            % (tally["nodes_per_ray"], F_BVH_NODE, tally["tris_per_ray"], F_BVH_TRI, F_SHADE_DIFFUSE), **tally},
+            {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+             "algorithmic_bytes_per_launch": bytes_,
+             "note": "algorithmic = 64 B per node entered + 64 B per triangle tested + 16 B radiance per sample; the upper tree levels "
+                     "are served by L2 / Infinity Cache, so achieved may exceed what HBM itself delivers"})
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
 
     import torch  # first: the shim must bind to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -131,13 +227,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.rehearse:
+        raise SystemExit("--gpus %d but only %d device(s) visible (use --rehearse to share devices; not a measurement)" % (world, ndev))
+    dev_idx = local_rank % ndev
+    torch.cuda.set_device(dev_idx)
+    rehearsal = world > ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_idx))
 
     from oclpathtracer_amd import adl, scene, shim
     from oclpathtracer_amd.distributed import StripeImage
@@ -146,21 +250,20 @@ def main():
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
 
     assert adl.init(adl.TYPE_HIP), "adl.init failed"
-    dev = adl.DeviceUtils.allocate(adl.TYPE_HIP, adl.Config(local_rank))
+    dev = adl.DeviceUtils.allocate(adl.TYPE_HIP, adl.Config(dev_idx))
     lib = shim.load()
-    dev.setOption(shim.PT_OPT_TRACE_VARIANT, args.variant)
     dev.setOption(shim.PT_OPT_QUAD_FILTER, args.quad_filter)
     dev.setOption(shim.PT_OPT_ACCEL, args.accel)
     img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True)
-
-    def step():
-        img.render(spp, frame_begin=0, max_bounces=depth)
-        img.gather()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def step():
+        img.render(spp, frame_begin=0, max_bounces=depth)
+        img.gather()
 
     for _ in range(args.warmup):
         step()
@@ -175,7 +278,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -184,8 +287,9 @@ def main():
     shim.check(lib.pt_profile_query(dev._h, shim.PT_PROF_TRACE, ctypes.byref(tot_ms), ctypes.byref(launches)))
     fold_ms, fold_n = ctypes.c_double(), ctypes.c_uint64()
     shim.check(lib.pt_profile_query(dev._h, shim.PT_PROF_FOLD, ctypes.byref(fold_ms), ctypes.byref(fold_n)))
+    shim.check(lib.pt_profile_enable(dev._h, 0))
     st = img.read_stats()
-    counters = torch.tensor([st["samples"], st["rays"]], dtype=torch.float64, device="cuda")
+    counters = torch.tensor([st["samples"], st["rays"]], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     total_samples, total_rays = float(counters[0].item()), float(counters[1].item())
@@ -194,73 +298,76 @@ def main():
         samples_per_step = W * H * spp
         assert total_samples == samples_per_step * args.steps, (total_samples, samples_per_step * args.steps)
         value = samples_per_step * args.steps / dt / 1e6
+        step_ms = dt / args.steps * 1e3
         out = {
             "metric": "Msamples/sec (pixels x spp / s), cornellbox.bin %dx%d" % (W, H),
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (cornellbox.bin scene, seeded per-pixel RNG of the reference)",
             "config": {"workload": "cornellbox.bin %dx%d, %d spp, depth %d, full path (BASELINE configs[2])" % (W, H, spp, depth),
                        "sharding": "%d-row image stripes round-robin over %d rank(s), RCCL gather to rank 0" % (args.stripe_rows, world),
-                       "rays_per_sample": total_rays / total_samples},
+                       "rays_per_sample": total_rays / total_samples, "timed_region_s": dt},
         }
-        if args.soup:
-            out["metric"] = "Msamples/sec (pixels x spp / s), %d-triangle soup %dx%d" % (len(tris), W, H)
-            out["config"]["workload"] = "soup of %d triangles (BASELINE configs[4] generator) %dx%d, %d spp, depth %d, accel %d" % (
-                len(tris), W, H, spp, depth, args.accel)
-            out["roofline"] = None
-            out["kernels"] = {"pt_trace_kernel_ms_total": tot_ms.value, "pt_trace_kernel_launches": int(launches.value),
-                              "pt_fold_kernel_ms_total": fold_ms.value}
-            print(json.dumps(out))
-            sys.stdout.flush()
-            img.release()
-            adl.DeviceUtils.deallocate(dev)
-            if world > 1:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
-        cpu, tallies = (None, None)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu, tallies = cpu_baseline(tris, mats, depth)
-        # roofline of pt_trace_kernel on rank 0: algorithmic work of ONE launch / its mean duration
+        if rehearsal:
+            out["rehearsal"] = "%d ranks share %d device(s), gloo gather through the host: code-path check, NOT a scaling measurement" % (world, ndev)
         n_launch = max(int(launches.value), 1)
         avg_ms = tot_ms.value / n_launch
         rank_samples = st["samples"] / n_launch
         rank_rays = st["rays"] / n_launch
-        if tallies is not None:
-            fpr = flops_per_ray_from_tallies(tallies)
-            basis = "outcome-weighted (SURVEY S8d) from the cpu_baseline sample's tallies"
+        out["kernels"] = {"pt_trace_kernel_ms_total": tot_ms.value, "pt_trace_kernel_launches": n_launch,
+                          "pt_fold_kernel_ms_total": fold_ms.value, "pt_fold_kernel_launches": int(fold_n.value)}
+        cpu = None
+        if args.soup:
+            out["metric"] = "Msamples/sec (pixels x spp / s), %d-triangle soup %dx%d" % (len(tris), W, H)
+            out["config"]["workload"] = "soup of %d triangles (BASELINE configs[4] generator) %dx%d, %d spp, depth %d, accel %d" % (
+                len(tris), W, H, spp, depth, args.accel)
+            if args.accel != 1 and world == 1:
+                tally = bvh_tallies(dev, lib, shim, tris, mats, W, H, depth)
+                out["roofline"], out["roofline_hbm"] = soup_roofline(tally, rank_rays, rank_samples, avg_ms)
+            else:
+                out["roofline"] = None
         else:
-            # no CPU leg in this run (N > 1 or --no-cpu-baseline): outcome mix of the committed golden
-            # tallies (tests/golden/work_counters.json, oracle, same scene and depth cap 16)
-            try:
-                with open(os.path.join(ROOT, "tests", "golden", "work_counters.json")) as f:
-                    fpr = flops_per_ray_from_tallies(json.load(f)["cornell_64x64_f8_d16"])
-                basis = "outcome-weighted (SURVEY S8d) from tests/golden/work_counters.json (cornell_64x64_f8_d16)"
-            except (OSError, KeyError, ValueError):
-                fpr = 36 * 52.0 + 130.0
-                basis = "fallback tri_tests x 52 + 130 shading"
-        flops = rank_samples * (F_GEN + F_ACC) + rank_rays * fpr
-        tfl = flops / (avg_ms * 1e-3) / 1e12
-        pmc = pmc_traffic()
-        tr_traffic = fo_traffic = None
-        if pmc is not None:
-            tr_traffic = pmc["pt_trace_kernel"]["hbm_bytes_per_sample"] * rank_samples
-            fo_traffic = pmc["pt_fold_kernel"]["hbm_bytes_per_sample"] * rank_samples
-        out["roofline"] = {
-            "bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
-            "traffic": tr_traffic, "kernel": "pt_trace_kernel", "avg_launch_ms": avg_ms, "launches": n_launch,
-            "algorithmic_flops_per_launch": flops, "flops_per_ray": fpr, "flops_basis": basis,
-            "traffic_basis": (pmc["file"] + ": measured HBM bytes/sample x samples of this launch") if pmc else None,
-            "note": "FP32 vector-ALU bound, no MFMA (no dense contraction); the f32 MFMA peak equals the VALU peak on gfx950",
-        }
-        gbs = rank_samples * BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
-        out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                               "traffic": (tr_traffic + fo_traffic) if pmc else None,
-                               "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
-                               "note": "reference semantics: 16 B read + 16 B write of the pixel per sample; scene is 3.4 KB; "
-                                       "traffic = trace (radiance stores) + fold (radiance reads) kernels"}
-        out["kernels"] = {"pt_trace_kernel_ms_total": tot_ms.value, "pt_fold_kernel_ms_total": fold_ms.value,
-                          "pt_fold_kernel_launches": int(fold_n.value)}
+            tallies = None
+            if world == 1 and not args.no_cpu_baseline:
+                cpu, tallies = cpu_baseline(tris, mats, depth)
+            # roofline of pt_trace_kernel on rank 0: algorithmic work of ONE launch / its mean duration
+            if tallies is not None:
+                fpr = flops_per_ray_from_tallies(tallies)
+                basis = "outcome-weighted (SURVEY S8d) from the cpu_baseline sample's tallies"
+            else:
+                # no CPU leg in this run (N > 1 or --no-cpu-baseline): outcome mix of the committed golden
+                # tallies (tests/golden/work_counters.json, oracle, same scene and depth cap 16)
+                try:
+                    with open(os.path.join(ROOT, "tests", "golden", "work_counters.json")) as f:
+                        fpr = flops_per_ray_from_tallies(json.load(f)["cornell_64x64_f8_d16"])
+                    basis = "outcome-weighted (SURVEY S8d) from tests/golden/work_counters.json (cornell_64x64_f8_d16)"
+                except (OSError, KeyError, ValueError):
+                    fpr = 36 * 52.0 + 130.0
+                    basis = "fallback tri_tests x 52 + 130 shading"
+            flops = rank_samples * (F_GEN + F_ACC) + rank_rays * fpr
+            tfl = flops / (avg_ms * 1e-3) / 1e12
+            pmc = pmc_traffic()
+            tr_traffic = fo_traffic = None
+            if pmc is not None:
+                tr_traffic = pmc["pt_trace_kernel"]["hbm_bytes_per_sample"] * rank_samples
+                fo_traffic = pmc["pt_fold_kernel"]["hbm_bytes_per_sample"] * rank_samples
+            out["roofline"] = {
+                "bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
+                "traffic": tr_traffic, "kernel": "pt_trace_kernel", "avg_launch_ms": avg_ms, "launches": n_launch,
+                "algorithmic_flops_per_launch": flops, "flops_per_ray": fpr, "flops_basis": basis,
+                "traffic_basis": (pmc["file"] + ": measured HBM bytes/sample x samples of this launch") if pmc else None,
+                "note": "FP32 vector-ALU bound, no MFMA (no dense contraction); the f32 MFMA peak equals the VALU peak on gfx950",
+            }
+            # the 32 B/sample of the reference are moved by trace + fold + framebuffer together: over the step
+            gbs = (W * H * spp) * BYTES_PER_SAMPLE / (step_ms * 1e-3) / 1e9
+            out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                   "traffic": (tr_traffic + fo_traffic) if pmc else None,
+                                   "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
+                                   "note": "reference semantics: 16 B read + 16 B write of the pixel per sample, over the whole "
+                                           "step (all ranks); scene is 3.4 KB; traffic = trace (radiance stores) + fold "
+                                           "(radiance reads) kernels of rank 0"}
+        if world == 1 and not args.soup and not args.no_extra_configs:
+            out["extra"] = {"configs": extra_configs(dev, lib, shim, scene, adl, fence, args)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
@@ -272,6 +379,45 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extra_configs(dev, lib, shim, scene, adl, fence, args):
+    """The other single-GPU BASELINE configurations, timed in this process after the headline region
+    (same fence / perf_counter bracket)."""
+    from oclpathtracer_amd.distributed import StripeImage
+
+    res = {}
+    # configs[1]: cornellbox 512x512, 64 spp, depth cap 2 ("direct lighting only")
+    tris, mats = scene.load_model()
+    img = StripeImage(dev, tris, mats, 512, 512, want_stats=True)
+    steps = 200
+    dt = time_render(img, fence, steps, 5, 64, 2)
+    img.release()
+    res["configs[1]"] = {"workload": "cornellbox.bin 512x512, 64 spp, depth 2", "value": 512 * 512 * 64 * steps / dt / 1e6,
+                         "unit": "Msamples/s", "steps": steps, "ms_per_step": dt / steps * 1e3}
+    # configs[4] scene on ONE GPU at full size: 10^6-triangle soup, 1024x1024, 256 spp, depth 16, LBVH
+    tris, mats = scene.make_soup(1_000_000)
+    img = StripeImage(dev, tris, mats, 1024, 1024, want_stats=True)
+    img.render(4, frame_begin=0, max_bounces=16)   # builds the LBVH, warms the caches
+    img.gather()
+    fence()
+    img.reset_stats()
+    shim.check(lib.pt_profile_enable(dev._h, 1))
+    shim.check(lib.pt_profile_reset(dev._h))
+    dt = time_render(img, fence, 1, 0, 256, 16)
+    tot_ms, launches = ctypes.c_double(), ctypes.c_uint64()
+    shim.check(lib.pt_profile_query(dev._h, shim.PT_PROF_TRACE, ctypes.byref(tot_ms), ctypes.byref(launches)))
+    shim.check(lib.pt_profile_enable(dev._h, 0))
+    st = img.read_stats()
+    img.release()
+    tally = bvh_tallies(dev, lib, shim, tris, mats, 1024, 1024, 16)
+    n_launch = max(int(launches.value), 1)
+    rf, rf_hbm = soup_roofline(tally, st["rays"] / n_launch, st["samples"] / n_launch, tot_ms.value / n_launch)
+    res["configs[4]"] = {"workload": "10^6-triangle soup 1024x1024, 256 spp, depth 16, LBVH, 1 GPU (BASELINE names 8)",
+                         "value": 1024 * 1024 * 256 / dt / 1e6, "unit": "Msamples/s", "steps": 1, "ms_per_step": dt * 1e3,
+                         "rays_per_sample": st["rays"] / max(st["samples"], 1), "trace_launches": n_launch,
+                         "roofline": rf, "roofline_hbm": rf_hbm}
+    return res
 
 
 if __name__ == "__main__":

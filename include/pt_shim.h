@@ -77,14 +77,20 @@ uint64_t pt_device_peak_memory(pt_device_t dev); /* Device::getPeakMemory  (Adl.
 int pt_device_num_cus(pt_device_t dev);          /* DeviceUtils::getNCUs               */
 
 /* Plumbing, no reference counterpart: run this handle's work on an existing hipStream_t
- * (e.g. torch's current stream, so torch.distributed collectives order after renders).
- * NULL restores the handle's own stream. */
+ * (e.g. a torch stream, so torch.distributed collectives can be ordered after renders with
+ * stream events).  NULL restores the handle's own (non-blocking) stream.  A caller whose
+ * "stream handle 0" means the legacy default stream (torch's default stream reports 0) must
+ * pass PT_STREAM_LEGACY, HIP's own sentinel hipStreamLegacy, so that it is not mistaken for NULL. */
+#define PT_STREAM_LEGACY ((void*)1)
 int pt_device_set_stream(pt_device_t dev, void* hip_stream);
 void* pt_device_get_stream(pt_device_t dev);
 
 /* DeviceUtils::waitForCompletion(device) -> clFinish : Adl/Adl.cpp:210-213, AdlCL.cpp:282-285.
  * NOTE: with frame batching enabled (pt_device_set_option) this does not force deferred
- * GenerateColors frames to execute; observing a buffer, pt_flush or an event does. */
+ * GenerateColors frames to execute; observing a buffer, pt_flush or an event does.  Only launches
+ * whose three buffers are all shim-allocated and whose device pointers were never handed out
+ * (pt_buffer_device_ptr) are ever deferred -- memory the caller can reach behind this ABI
+ * (pt_buffer_wrap, pt_buffer_device_ptr) gets clFinish semantics: the launch runs at once. */
 int pt_sync(pt_device_t dev);
 /* DeviceUtils::flush -> clFlush : AdlCL.cpp:303-306.  Submits deferred frames. */
 int pt_flush(pt_device_t dev);
@@ -101,15 +107,13 @@ enum pt_option {
     /* Device::toggleProfiling(PROFILE_RETURN_TIME) (Adl.h:171): launches synchronise and
      * return their duration in ms (AdlKernelUtilsCL.cpp:470-487). */
     PT_OPT_PROFILE_RETURN_TIME = 2,
-    /* which trace kernel renders: 0 = library default, 1 = lane-regenerating waves,
-     * 2 = octant-sorted workgroups (rays regrouped by direction octant through LDS every bounce).
-     * All variants produce identical pixels. */
+    /* which trace kernel renders: 0 = library default, 1 = lane-regenerating waves (the only one
+     * shipped; an octant-sorted experiment of round 1 was measured slower and removed). */
     PT_OPT_TRACE_VARIANT = 3,
     /* conservative pass-1 filter of the closest-hit search, for A/B timing and parity tests:
-     * 0 = the strongest the uploaded scene allows, 1 = independent triangles, 2 = at most the
-     * pair filter (shared cross product), 3 = at most the shared-u filter (one numerator decides
-     * both triangles of an (a,b,c),(c,d,a) pair), 4 = at most its packed Pluecker form (two quads
-     * per instruction).  All settings produce identical pixels. */
+     * 0 = the strongest the uploaded scene allows, 1..3 = independent triangles (pt_tri_pass1),
+     * 4 = the packed shared-u filter when the scene is made of (a,b,c),(c,d,a) quads (two quads per
+     * instruction, pt_quad3_pass1; same as 0).  All settings produce identical pixels. */
     PT_OPT_QUAD_FILTER = 4,
     /* closest-hit search: 0 = brute force below 512 triangles, LBVH from 512 on;
      * 1 = brute force (the reference's intersectWorld loop, GenerateColors.cl:137-154); 2 = LBVH
@@ -117,7 +121,11 @@ enum pt_option {
      * applies the same exact triangle test to a conservative candidate set and resolves ties to the
      * lower index, as the reference's ascending loop does; see csrc/pt_bvh.hip for the one
      * theoretical caveat (rays within ~0.05 degrees of a triangle's plane). */
-    PT_OPT_ACCEL = 5
+    PT_OPT_ACCEL = 5,
+    /* measurement only (bench.py's roofline of LBVH runs): 1 = renders that pass a stats buffer and
+     * take the LBVH use the tallying build of the search, which adds its work counters to
+     * stats[PT_STAT_BVH_*].  Same pixels; slower; never the timed kernel.  Default 0. */
+    PT_OPT_BVH_TALLY = 6
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);
@@ -132,7 +140,9 @@ int pt_buffer_wrap(pt_device_t dev, void* device_ptr, size_t bytes, pt_buffer_t*
 /* ~Buffer -> DeviceCL::deallocate : Adl.inl:153-165, AdlCL.inl:251-268 */
 int pt_buffer_free(pt_buffer_t buf);
 size_t pt_buffer_size(pt_buffer_t buf);
-void* pt_buffer_device_ptr(pt_buffer_t buf); /* Buffer<T>::getInternalObject / m_ptr */
+/* Buffer<T>::getInternalObject / m_ptr.  Submits deferred frames that touch the buffer and
+ * switches frame batching off for it from now on (the caller can see the memory directly). */
+void* pt_buffer_device_ptr(pt_buffer_t buf);
 /* Buffer<T>::write / read (host) -> clEnqueueWrite/ReadBuffer : AdlCL.inl:297-340.
  * Asynchronous w.r.t. the host like the reference (non-blocking enqueue); the host range
  * must stay valid until pt_sync / the event.  ev may be NULL. */
@@ -146,7 +156,8 @@ int pt_buffer_copy(pt_buffer_t dst, pt_buffer_t src, size_t bytes, size_t dst_of
  * (pt_sync, or blocking != 0); NULL on failure. */
 void* pt_buffer_map(pt_buffer_t buf, size_t bytes, int blocking);
 /* Buffer<T>::returnHostPtr -> clEnqueueUnmapMemObject : AdlCL.inl:447-451.
- * Copies the staging range back to the device (asynchronously) and releases it. */
+ * Copies the mapped range (the `bytes` of the matching pt_buffer_map, no more) back to the
+ * device (asynchronously) and releases it. */
 int pt_buffer_unmap(pt_buffer_t buf, void* host_ptr);
 
 /* Page-locked host memory, so that pt_buffer_read / pt_buffer_write into it are truly asynchronous
@@ -223,7 +234,13 @@ typedef struct pt_render_params {
 int pt_local_rows(int height, int stripe_rows, int n_ranks, int rank);
 
 /* work counters accumulated by pt_render_frames when stats != NULL (uint64 each) */
-enum { PT_STAT_SAMPLES = 0, PT_STAT_RAYS = 1, PT_STAT_WORDS = 8 };
+enum {
+    PT_STAT_SAMPLES = 0, PT_STAT_RAYS = 1,
+    /* PT_OPT_BVH_TALLY renders only: box nodes entered, triangles tested, iterations of the waves'
+     * search loops, wave searches (one per wave per bounce) */
+    PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_ITERS = 4, PT_STAT_BVH_WAVES = 5,
+    PT_STAT_WORDS = 8
+};
 
 int pt_render_frames(pt_device_t dev, pt_buffer_t triangles, pt_buffer_t materials,
                      pt_buffer_t framebuffer, const pt_render_params* params,

@@ -38,9 +38,6 @@ static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
 #define PT_LDS_TRI_STRIDE 12    // dwords per triangle record in the LDS copy (p1, e1, e2, 3 pad)
 #define PT_LDS_TRI_MAX 256      // scenes up to this many triangles keep the copy (12 KiB per workgroup)
-#ifndef PT_SORT_THREADS
-#define PT_SORT_THREADS 512    // 8 waves per workgroup (variant 2: octant-sorted)
-#endif
 
 struct PtTraceParams {
     const PtPrepTriangle* tris;
@@ -84,19 +81,16 @@ hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, 
 #define PT_P1_STRIDE 24  // floats per quad pair: nx ny nz e2x e2y e2z Kx Ky Kz dhi, each {quad 2p, quad 2p+1}, 4 pad
 static inline size_t ptk_p1tab_floats(int ntri) { return (size_t)((ntri / 2 + 1) / 2) * PT_P1_STRIDE; }
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
-// quads: 0 = none; 1 = ntri is even and every pair (2k, 2k+1) has e2' == -e2 (pt_quad_pass1);
-//        2 = additionally p1' == p3 and the margins are prepared (pt_quad2_pass1)
-//        3 = as 2, evaluated from the packed table p.p1tab (pt_quad3_pass1)
-// bvh: traverse p.bvh instead of the brute-force two-pass search (variant 1 only)
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, bool bvh, hipStream_t s);
+// quads: 0 = independent triangles (pt_tri_pass1); 3 = ntri is even, every pair (2k, 2k+1) is a quad
+//        (a,b,c),(c,d,a), the margins and the packed table p.p1tab are prepared (pt_quad3_pass1)
+// bvh: traverse p.bvh instead of the brute-force two-pass search
+// tally: (bvh only) the measurement variant that adds the search's work counters to p.stats[2..5]
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s);
 size_t ptk_bvh_node_count(int ntri);
 size_t ptk_bvh_temp_bytes(int ntri);
 hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, void* temp, size_t temp_bytes, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
-#ifndef PT_DEFAULT_SORTED
-#define PT_DEFAULT_SORTED 0  // which variant PT_OPT_TRACE_VARIANT = 0 (auto) picks
-#endif
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);
 hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width, int height, int stripe_rows,
                                 int n_ranks, int slab_rows, hipStream_t s);
@@ -106,4 +100,4 @@ hipError_t ptk_math(const float* in, float* out, int n, hipStream_t s);
 // dynamic LDS of variant 1: the triangle table (scenes up to PT_LDS_TRI_MAX) + one camera-ray slot
 // per sample of every wave's current batch
 size_t ptk_trace_lds_bytes(int ntri);
-int ptk_trace_blocks_per_cu(bool sorted, int ntri);
+int ptk_trace_blocks_per_cu(int ntri);

@@ -183,79 +183,6 @@ PTK_DEV PtTriRec pt_load_tri(pt_const_f32p T, int i)
 #ifndef PT_VALIDATE_FILTER
 #define PT_VALIDATE_FILTER 0  // diagnostic: check the pass-1 filter against the reference predicate
 #endif
-#ifndef PT_QUAD_PAIRS
-#define PT_QUAD_PAIRS 1  // use pt_quad_pass1 when the scene is made of (2k, 2k+1) quads
-#endif
-#ifndef PT_TWO_PASS
-#define PT_TWO_PASS 1  // 1: two-pass closest hit (uniform det+u pass, per-lane survivor pass); 0: one flat pass
-#endif
-#ifndef PT_TRACK_UV
-#define PT_TRACK_UV 0  // 1: carry (u,v) of the closest hit through the loop; 0: recompute them for the winner
-#endif
-
-// Straight-line form: every lane evaluates the whole test and the five early returns of the
-// reference (:100,:109,:117,:125) become one predicate.  Values computed past a failed test are
-// never observed, so the accepted (t,u,v,index) are those of the branchy form bit for bit.  With
-// lane-level path regeneration the 64 rays of a wave are incoherent: the branchy form skipped
-// almost nothing (every stage had a live lane) yet paid ~20 SALU exec-mask/branch instructions
-// per triangle (rocprofv3: 757 SALU per 2100 VALU per wave-bounce).
-template <bool DET_BOUNDED>
-PTK_DEV void pt_tri_test(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
-{
-    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
-    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
-    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
-    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    // (:100) returns when det < 1e-8f || -det > 1e-8f; the second clause implies the first
-    bool ok = !(det < 1e-8f);
-    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
-    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
-    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    ok &= !(u < 0.0f) & !(u > 1.0f);  // :109
-    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
-    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
-    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
-    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
-    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
-    ok &= (tt > 0.0f) & (tt < tmax);  // :125
-    tmax = ok ? tt : tmax;
-    hidx = ok ? i : hidx;
-#if PT_TRACK_UV
-    hu = ok ? u : hu;
-    hv = ok ? v : hv;
-#else
-    (void)hu; (void)hv;  // recomputed once for the winner: pt_hit_uv
-#endif
-}
-
-// (u, v) of the winning triangle, recomputed with the arithmetic of the test above from the
-// triangle's record (per-lane vector loads): the same operations on the same operands give the
-// same bits as carrying (u, v) through the 36-triangle loop, for 2 fewer v_cndmask per triangle.
-template <bool DET_BOUNDED>
-PTK_DEV void pt_hit_uv(const PtPrepTriangle* tris, int hidx, const f3& o, const f3& d, float& hu, float& hv)
-{
-    const float* t = reinterpret_cast<const float*>(tris + hidx);
-    const float4 q0 = *reinterpret_cast<const float4*>(t);      // p1.xyz e1.x
-    const float4 q1 = *reinterpret_cast<const float4*>(t + 4);  // e1.yz e2.xy
-    const float e2z = t[8];
-    PtTriRec r;
-    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
-    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
-    r.e2x = q1.z; r.e2y = q1.w; r.e2z = e2z;
-    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
-    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
-    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
-    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
-    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
-    hu = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
-    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
-    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
-    hv = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-}
-
 // ---- two-pass closest hit -------------------------------------------------------------------------
 // SIMT executes all 44 instructions of the flat test for every lane, but only 9 % of the
 // (ray, triangle) pairs get past the u test (:109) -- 50 % are culled at :100, 41 % fail :109.
@@ -375,31 +302,6 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
 // (Software-pipelining pass 2 -- fetching the next survivor's record during the current test --
 // was measured slower: 64.8 ms against 61.1 ms; the register copies cost more than the LDS latency
 // that 7 waves per SIMD already hide.)
-// Pass 1 for a QUAD: triangles 2k = (a,b,c) and 2k+1 = (c,d,a) of one quad (RaytraceTest.cpp:186-187)
-// have e2' = a - c = -(c - a) = -e2 exactly, hence pvec' = cross(dir, e2') = -pvec component for
-// component (round-to-nearest is sign-symmetric; only the sign of an exactly-zero component can
-// differ), det' = -(e1'.pvec) and un' = -(tvec'.pvec) with the same magnitudes as the reference's
-// own evaluation.  The conservative bounds of pt_tri_pass1 compare magnitudes only (a zero of either
-// sign passes them), so the second triangle's filter needs no cross product: 14 VALU instead of 20.
-// The host enables this only when EVERY pair (2k, 2k+1) of the scene satisfies e2' == -e2
-// (checked by pt_prep_kernel); returns the two mask bits (bit 0: triangle 2k, bit 1: 2k+1).
-PTK_DEV void pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float bp1z, float be1x, float be1y, float be1z,
-                           const f3& o, const f3& d, pt_lanes& okA, pt_lanes& okB)
-{
-    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y));
-    float pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z));
-    float pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
-    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
-    float tax = o.x - a.p1x, tay = o.y - a.p1y, taz = o.z - a.p1z;
-    float unA = pt_fma(taz, pvz, pt_fma(tay, pvy, tax * pvx));
-    okA = PT_LANES(!(unA < -1e-24f)) & PT_LANES(!(unA > detA * 1.000001f));
-    // second triangle: det' = -q, un' = -r;  !(un' < -1e-24) & !(un' > det' * 1.000001f)
-    float q = pt_fma(be1z, pvz, pt_fma(be1y, pvy, be1x * pvx));
-    float tbx = o.x - bp1x, tby = o.y - bp1y, tbz = o.z - bp1z;
-    float r = pt_fma(tbz, pvz, pt_fma(tby, pvy, tbx * pvx));
-    okB = PT_LANES(!(r > 1e-24f)) & PT_LANES(!(r < q * 1.000001f));
-}
-
 // Pass 1 for a quad (a,b,c),(c,d,a) in MODE 2: ONE u numerator decides both triangles.
 //
 // In A's barycentric frame the second triangle B is the strip u in [-1, 0]: with p1' = c,
@@ -424,19 +326,6 @@ PTK_DEV void pt_quad_pass1(const PtTriRec& a, float bp1x, float bp1y, float bp1z
 // (pt_prep_quad_margins_kernel).  A NaN anywhere fails every comparison and is kept.
 // 25 VALU per quad instead of 34.  tools/validate_filter.py re-checks every dropped pair against
 // the literal reference predicate (profiles/r01/filter_validation.txt).
-PTK_DEV void pt_quad2_pass1(const PtTriRec& a, float delta3, float delta1, const f3& o, const f3& d, pt_lanes& okA, pt_lanes& okB)
-{
-    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y));
-    float pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z));
-    float pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
-    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
-    float tax = o.x - a.p1x, tay = o.y - a.p1y, taz = o.z - a.p1z;
-    float unA = pt_fma(taz, pvz, pt_fma(tay, pvy, tax * pvx));
-    float m = detA * 1.000002f;
-    okA = PT_LANES(!(unA < -1e-24f)) & PT_LANES(!(unA > m));
-    okB = PT_LANES(!(unA > delta1)) & PT_LANES(!(unA < -(m + delta3)));
-}
-
 // Pass 1 in MODE 3: the shared-u filter of mode 2 evaluated in Pluecker form, two quads per
 // instruction.  tools/ubench_issue (profiles/r01/ubench_issue.log): on gfx950 an fp32 FMA/MUL/ADD
 // whose operands are all VGPRs issues at double rate (~2.7 cycles per wave), ANY SGPR operand
@@ -497,7 +386,7 @@ PTK_DEV void pt_quad3_pass1(pt_const_f32p t, const PtRay3& r, pt_f2& un, pt_f2& 
 #define PT_STAMP(var) do { } while (0)
 #endif
 
-// QUADS: 0 = independent triangles, 1 = pt_quad_pass1, 2 = pt_quad2_pass1, 3 = pt_quad3_pass1
+// QUADS: 0 = independent triangles (pt_tri_pass1), 3 = packed shared-u filter (pt_quad3_pass1)
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx,
@@ -507,9 +396,9 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
 #if PT_STAMPS
     unsigned long long ta = 0, tb = 0;
 #endif
-    (void)vstat; (void)p1_ticks; (void)delta1; (void)ray_radius; (void)p1tab; (void)p1_lo; (void)p1_hi;
+    (void)vstat; (void)p1_ticks; (void)ray_radius; (void)p1tab; (void)p1_lo; (void)p1_hi;
     unsigned steps = 0;  // pass-2 iterations of this wave (diagnostics only)
-    // mode 2: the assumptions of pt_quad2_pass1's error bound, checked for THIS ray
+    // the assumptions of the shared-u error bound (derivation above pt_quad3_pass1), checked for THIS ray
     bool tame = true;
     PtRay3 r3v;
     if (QUADS == 3 && DET_BOUNDED) {
@@ -517,7 +406,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         const f3 M = cross3(oc, d);
         r3v.dxy = pt_f2{ d.x, d.y }; r3v.dzMx = pt_f2{ d.z, M.x }; r3v.Myz = pt_f2{ M.y, M.z };
     }
-    if (QUADS >= 2 && DET_BOUNDED) {
+    if (QUADS == 3 && DET_BOUNDED) {
         float dd = pt_fma(d.z, d.z, pt_fma(d.y, d.y, d.x * d.x));
         tame = (dd <= 1.001f) & (__builtin_fabsf(o.x - PT_EYE_X) <= ray_radius) &
                (__builtin_fabsf(o.y - PT_EYE_Y) <= ray_radius) & (__builtin_fabsf(o.z - PT_EYE_Z) <= ray_radius);
@@ -541,24 +430,6 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
                 }
             }
             if (!tame) m = n == 32 ? ~0u : (1u << n) - 1u;
-        } else if (QUADS == 2 && DET_BOUNDED) {
-            for (int j = 0; j < n; j += 2) {
-                const PtTriRec a = pt_load_tri(T, base + j);
-                const float delta3 = T[16 * (base + j + 1) + 9];  // pad0[0] of the pair's second record
-                pt_lanes okA, okB;
-                pt_quad2_pass1(a, delta3, delta1, o, d, okA, okB);
-                m = pt_push_flag(pt_push_flag(m, okA), okB);
-            }
-            if (!tame) m = n == 32 ? ~0u : (1u << n) - 1u;
-        } else if (QUADS == 1 && DET_BOUNDED) {
-            // ntri is even and every (2k, 2k+1) is a quad; base and n are even
-            for (int j = 0; j < n; j += 2) {
-                const PtTriRec a = pt_load_tri(T, base + j);
-                pt_const_f32p tb = T + 16 * (base + j + 1);
-                pt_lanes okA, okB;
-                pt_quad_pass1(a, tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], o, d, okA, okB);
-                m = pt_push_flag(pt_push_flag(m, okA), okB);
-            }
         } else {
             PtTriRec a = pt_load_tri(T, base);
             int j = 0;
@@ -592,28 +463,11 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             atomicAdd(&vstat[1], (unsigned long long)__popc(mx));        // pairs the reference keeps
             atomicAdd(&vstat[2], (unsigned long long)__popc(m));         // pairs the filter keeps
             atomicAdd(&vstat[3], (unsigned long long)__popc(mx & ~m));   // VIOLATIONS: must stay 0
-            if (QUADS >= 2 && DET_BOUNDED && tame) {
-                // headroom of pt_quad2_pass1's error bounds: the largest observed
-                // |un' + unA| / delta1 and (|det' - detA| c + |un' + unA|) / delta3 (both must be <= 1)
+            if (QUADS == 3 && DET_BOUNDED && tame) {
+                // how far mode 3's own roundings are from the reference's floats, relative to the slack
+                // budgeted for that: |un_here - un_ref| / deltaP and |det_here c - det_ref c| / deltaD
                 float r1 = 0.0f, r3 = 0.0f;
-                for (int jj = 0; jj + 1 < n; jj += 2) {
-                    const PtTriRec a = pt_load_tri(T, base + jj), b = pt_load_tri(T, base + jj + 1);
-                    const float delta3 = T[16 * (base + jj + 1) + 9];
-                    float pvx = pt_fma(d.y, a.e2z, -(d.z * a.e2y)), pvy = pt_fma(d.z, a.e2x, -(d.x * a.e2z)), pvz = pt_fma(d.x, a.e2y, -(d.y * a.e2x));
-                    float detA = pt_fma(a.e1z, pvz, pt_fma(a.e1y, pvy, a.e1x * pvx));
-                    float unA = pt_fma(o.z - a.p1z, pvz, pt_fma(o.y - a.p1y, pvy, (o.x - a.p1x) * pvx));
-                    float qvx = pt_fma(d.y, b.e2z, -(d.z * b.e2y)), qvy = pt_fma(d.z, b.e2x, -(d.x * b.e2z)), qvz = pt_fma(d.x, b.e2y, -(d.y * b.e2x));
-                    float detB = pt_fma(b.e1z, qvz, pt_fma(b.e1y, qvy, b.e1x * qvx));
-                    float unB = pt_fma(o.z - b.p1z, qvz, pt_fma(o.y - b.p1y, qvy, (o.x - b.p1x) * qvx));
-                    float e1 = __builtin_fabsf(unB + unA), e2 = __builtin_fabsf(detB - detA);
-                    float q1 = e1 / delta1, q3 = (e2 * 1.000001f + e1) / delta3;
-                    r1 = q1 > r1 ? q1 : r1;
-                    r3 = q3 > r3 ? q3 : r3;
-                }
-                if (QUADS == 3) {
-                    // mode 3 instead: how far its own roundings are from the reference's floats, relative to
-                    // the slack budgeted for that: |un_here - un_ref| / deltaP and |det_here c - det_ref c| / deltaD
-                    r1 = r3 = 0.0f;
+                {
                     const float deltaP = -p1_lo, deltaD = deltaP * (128.0f / 192.0f);
                     for (int jj = 0; jj + 1 < n; jj += 4) {
                         pt_f2 unp, thp;
@@ -659,6 +513,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
     return steps;
 }
 
+PTK_DEV unsigned pt_lane_id();
 // ---- closest hit through the LBVH (pt_bvh.hip) -----------------------------------------------------
 // Stackless traversal along the nodes' miss links; every lane walks its own ray.  At a leaf the
 // reference's exact test runs with pt_tri_pass2's arithmetic; because leaves are met in tree order,
@@ -707,14 +562,12 @@ PTK_DEV bool pt_slab(const float4& bmin, const float4& bmax, const f3& o, float 
 // level at most, and a radix tree over 64-bit keys has at most 64 levels).  Leaves are tested as
 // soon as their box is hit; tmax then prunes everything farther.
 #define PT_BVH_STACK 64
-template <bool DET_BOUNDED>
+// TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..5]:
+// nodes entered, triangles tested, iterations of the wave's loop, wave searches.  Never the timed kernel.
+template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepTriangle* __restrict__ tris, int ntri, const f3& o, const f3& d,
                               bool alive, float& tmax, float& hu, float& hv, int& hidx, unsigned long long* bstat = nullptr)
 {
-#ifndef PT_BVH_STATS
-#define PT_BVH_STATS 0  // DIAGNOSTIC build: stats[2..5] = nodes entered, leaves tested, wave loop iterations, rays
-#endif
-    (void)bstat;
     unsigned c_nodes = 0, c_leaves = 0, c_iters = 0;
     // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
     // boxes' margin); a zero component gives +-Inf
@@ -770,16 +623,19 @@ PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepT
             cur = next;
         }
     }
-#if PT_BVH_STATS
-    if (bstat && alive) {
-        atomicAdd(&bstat[0], (unsigned long long)c_nodes);
-        atomicAdd(&bstat[1], (unsigned long long)c_leaves);
-        atomicAdd(&bstat[2], (unsigned long long)c_iters);
-        atomicAdd(&bstat[3], 1ull);
+    if (TALLY && bstat) {
+        unsigned long long n = alive ? c_nodes : 0u, l = alive ? c_leaves : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            n += __shfl_down(n, off);
+            l += __shfl_down(l, off);
+        }
+        if (pt_lane_id() == 0) {
+            atomicAdd(&bstat[0], n);
+            atomicAdd(&bstat[1], l);
+            atomicAdd(&bstat[2], (unsigned long long)c_iters);
+            atomicAdd(&bstat[3], 1ull);
+        }
     }
-#else
-    (void)c_nodes; (void)c_leaves; (void)c_iters;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -796,72 +652,11 @@ struct PtPath {
     unsigned fl;    // frame index inside the chunk
 };
 
-// wave-uniform slice of the global sample queue
-struct PtQueue {
-    unsigned pix, end, frame;
-    unsigned row, col;  // local row / column of `pix` (kept incrementally: no per-lane division)
-    bool exhausted;
-};
-
 PTK_DEV unsigned pt_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 PTK_DEV unsigned pt_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
-// ---- regeneration: dead lanes take the next samples of the wave's range ------------------------
-PTK_DEV void pt_regenerate(const PtTraceParams& P, unsigned lane, PtQueue& q, PtPath& s, bool& alive)
-{
-    unsigned long long need = __ballot(!alive);
-    while (need != 0ull && !q.exhausted) {
-        if (q.pix == q.end) {
-            unsigned b = 0;
-            if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= P.total_batches) { q.exhausted = true; break; }
-            unsigned f = b / P.batches_per_frame;
-            unsigned bi = b - f * P.batches_per_frame;
-            q.frame = f;
-            q.pix = bi * P.batch;
-            unsigned e = q.pix + P.batch;
-            q.end = e < P.npix_local ? e : P.npix_local;
-            q.row = q.pix / (unsigned)P.width;  // one wave-uniform division per 256 samples
-            q.col = q.pix - q.row * (unsigned)P.width;
-        }
-        unsigned n_need = (unsigned)__popcll(need);
-        unsigned avail = q.end - q.pix;
-        unsigned take = n_need < avail ? n_need : avail;
-        unsigned rank = pt_mbcnt(need);
-        if (!alive && rank < take) {
-            s.lp = q.pix + rank;
-            s.fl = q.frame;
-            // local pixel -> (local row, column): walk from the range's (row, col); a wave takes
-            // at most 64 pixels at a time, so this loops once or twice unless the image is narrow
-            unsigned lr = q.row, x = q.col + rank;
-            while (x >= (unsigned)P.width) { x -= (unsigned)P.width; ++lr; }
-            // local row -> global row (image rows dealt to ranks in stripes)
-            unsigned grow = lr;
-            if (P.n_ranks > 1) {
-                unsigned sl = lr / (unsigned)P.stripe_rows;
-                unsigned within = lr - sl * (unsigned)P.stripe_rows;
-                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
-            }
-            unsigned gid = grow * (unsigned)P.width + x;
-            int frame = P.frame_begin + (int)s.fl;
-            s.seed = gid + pt_hash_u32((uint32_t)frame);                           // :308
-            pt_generate_ray((int)x, (int)grow, P.width, P.height, s.seed, s.o, s.d);  // :310
-            s.mask = mk3(1.0f, 1.0f, 1.0f);
-            s.L = mk3(0.0f, 0.0f, 0.0f);
-            s.bounce = 0;
-            alive = true;
-        }
-        q.pix += take;
-        q.col += take;
-        while (q.col >= (unsigned)P.width) { q.col -= (unsigned)P.width; ++q.row; }
-        need = __ballot(!alive);
-    }
-}
-
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
-// HAVE_UV: the caller's closest-hit search carried (u,v); otherwise they are recomputed here
-template <bool DET_BOUNDED, bool HAVE_UV>
+template <bool DET_BOUNDED>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
                       unsigned& n_rays, unsigned& n_samples, unsigned long long* sub = nullptr)
 {
@@ -898,7 +693,6 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         int mid = __float_as_int(nid.w);
         mid = mid < 0 ? 0 : (mid >= P.nmat ? P.nmat - 1 : mid);  // never fault on a corrupt id
         f3 p = add3(s.o, scale3(s.d, tmax));
-        if (!HAVE_UV) pt_hit_uv<DET_BOUNDED>(P.tris, hidx, s.o, s.d, hu, hv);
         float w = 1.0f - hu - hv;
         f3 n = normalize3(add3(add3(scale3(N, hu), scale3(N, hv)), scale3(N, w)));
 
@@ -1091,7 +885,7 @@ PTK_DEV void pt_regenerate_bulk(const PtTraceParams& P, unsigned lane, PtQueueB&
     }
 }
 
-template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
+template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS, bool TALLY = false>
 PTK_DEV void pt_trace_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
@@ -1129,15 +923,12 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         if (__ballot(alive) == 0ull) break;
         PT_STAMP(t1);
 
-        // ---- intersectWorld (:137-154): every lane, wave-uniform triangle index -------------
-        // Two triangle records in flight: the scalar load of triangle i+1 is issued before the
-        // ~46 VALU ops of triangle i, so its latency is covered by this wave's own work.
+        // ---- intersectWorld (:137-154) ------------------------------------------------------
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
-#if PT_TWO_PASS
         unsigned p2steps = 0;
         if (QUADS == PT_ACCEL_BVH)
-            pt_intersect_bvh<DET_BOUNDED>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.stats ? P.stats + 2 : nullptr);
+            pt_intersect_bvh<DET_BOUNDED, TALLY>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.stats ? P.stats + 2 : nullptr);
         else
             p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
@@ -1154,25 +945,12 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 #else
         (void)p2steps;
 #endif
-#else
-        if (ntri > 0) {
-            PtTriRec a = pt_load_tri(T, 0);
-            int i = 0;
-            for (; i + 1 < ntri; i += 2) {
-                PtTriRec b = pt_load_tri(T, i + 1);
-                pt_tri_test<DET_BOUNDED>(a, i, s.o, s.d, tmax, hu, hv, hidx);
-                a = pt_load_tri(T, i + 2 < ntri ? i + 2 : i + 1);
-                pt_tri_test<DET_BOUNDED>(b, i + 1, s.o, s.d, tmax, hu, hv, hidx);
-            }
-            if (i < ntri) pt_tri_test<DET_BOUNDED>(a, i, s.o, s.d, tmax, hu, hv, hidx);
-        }
-#endif
 
         PT_STAMP(t2);
 #if PT_STAMPS == 2
-        if (alive) pt_shade<DET_BOUNDED, (PT_TWO_PASS || PT_TRACK_UV)>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
+        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
 #else
-        if (alive) pt_shade<DET_BOUNDED, (PT_TWO_PASS || PT_TRACK_UV)>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #endif
 #if PT_STAMPS
         PT_STAMP(t3);
@@ -1212,168 +990,11 @@ void pt_trace_kernel(const PtTraceParams P)
 
 // the LBVH search keeps a traversal stack and two boxes live: it gets the registers it asks for
 // (5 waves per SIMD) instead of the brute-force kernel's 7-wave diet
-template <bool DET_BOUNDED>
+template <bool DET_BOUNDED, bool TALLY>
 __global__ __launch_bounds__(PT_TRACE_THREADS)
 void pt_trace_bvh_kernel(const PtTraceParams P)
 {
-    pt_trace_body<DET_BOUNDED, false, PT_ACCEL_BVH>(P);
-}
-
-// ---- variant 2: rays regrouped by direction octant once per bounce ------------------------------
-// With regenerating lanes a wave's 64 rays point everywhere, so a triangle that is back-facing
-// (:100) for most of them is still front-facing for some, and every lane pays the full test.
-// Here the workgroup's live paths are counting-sorted by the sign octant of their direction
-// through LDS before every intersection pass (9 keys: 8 octants + "dead").  In an octant-pure
-// wave the cull decision of an axis-aligned triangle is the same for all 64 lanes, so after the
-// det stage (10 VALU) a wave-uniform branch skips the remaining 36 for the triangles nobody faces
-// (Cornell box: 22 of 36 survive on average instead of 36).  Every lane still evaluates its own
-// det and the same arithmetic as variant 1 for every triangle it does face: results are
-// bit-identical; only which lane carries which path changes.  Side effects: dead lanes collect in
-// the workgroup's last waves, so regeneration runs with full waves in ~1/6 of them instead of a
-// few lanes in all of them, and live paths are compacted into the fewest waves during the tail.
-struct PtSortShared {
-    float4 st[4][PT_SORT_THREADS];  // path state, one 16-B quarter per array: conflict-free b128 access
-    unsigned cnt[2][16];            // per-key counters, double-buffered across iterations
-};
-
-template <bool DET_BOUNDED>
-PTK_DEV bool pt_tri_test_cull(const PtTriRec& r, int i, const f3& o, const f3& d, bool alive, float& tmax, float& hu,
-                              float& hv, int& hidx)
-{
-    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
-    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
-    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
-    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    bool ok = alive & !(det < 1e-8f);              // :100 (see pt_tri_test)
-    if (__ballot(ok) == 0ull) return false;         // wave-uniform: nobody faces this triangle
-    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
-    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
-    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    ok &= !(u < 0.0f) & !(u > 1.0f);  // :109
-    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
-    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
-    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
-    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
-    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
-    ok &= (tt > 0.0f) & (tt < tmax);  // :125
-    tmax = ok ? tt : tmax;
-    hidx = ok ? i : hidx;
-    (void)hu; (void)hv;  // recomputed for the winner: pt_hit_uv
-    return true;
-}
-
-template <bool DET_BOUNDED>
-__global__ __launch_bounds__(PT_SORT_THREADS) void pt_trace_sorted_kernel(const PtTraceParams P)
-{
-    __shared__ PtSortShared sh;
-    const unsigned tid = threadIdx.x;
-    const unsigned lane = pt_lane_id();
-    pt_const_f32p T = (pt_const_f32p)(const float*)P.tris;
-    const int ntri = P.ntri;
-
-    if (tid < 32) (&sh.cnt[0][0])[tid] = 0u;
-    __syncthreads();
-
-    PtQueue q = { 0u, 0u, 0u, 0u, 0u, false };
-    bool alive = false;
-    PtPath s;
-    s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
-    s.mask = mk3(1.0f, 1.0f, 1.0f); s.L = mk3(0.0f, 0.0f, 0.0f);
-    s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
-    unsigned n_rays = 0, n_samples = 0;
-
-#if PT_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, c_regen = 0, c_sort = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_full = 0;
-#endif
-    for (unsigned it = 0;; ++it) {
-        PT_STAMP(t0);
-        pt_regenerate(P, lane, q, s, alive);
-        PT_STAMP(t1);
-
-        // ---- counting sort of the workgroup's paths by direction octant -------------------------
-        unsigned key = 8u;
-        if (alive) key = (s.d.x > 0.0f ? 4u : 0u) | (s.d.y > 0.0f ? 2u : 0u) | (s.d.z > 0.0f ? 1u : 0u);
-        unsigned* C = sh.cnt[it & 1u];
-        unsigned mycount = 0u, myrank = 0u;
-#pragma unroll
-        for (unsigned k = 0; k < 9u; ++k) {
-            unsigned long long bk = __ballot(key == k);
-            if (lane == k) mycount = (unsigned)__popcll(bk);
-            if (key == k) myrank = pt_mbcnt(bk);
-        }
-        unsigned woff = 0u;
-        if (lane < 9u) woff = atomicAdd(&C[lane], mycount);  // this wave's offset inside key `lane`
-        __syncthreads();
-        if (tid < 16u) sh.cnt[(it + 1u) & 1u][tid] = 0u;     // next iteration's counters
-        const uint4 c0 = *reinterpret_cast<const uint4*>(&C[0]);
-        const uint4 c1 = *reinterpret_cast<const uint4*>(&C[4]);
-        const unsigned b1 = c0.x, b2 = b1 + c0.y, b3 = b2 + c0.z, b4 = b3 + c0.w;
-        const unsigned b5 = b4 + c1.x, b6 = b5 + c1.y, b7 = b6 + c1.z, n_alive = b7 + c1.w;
-        if (n_alive == 0u) break;  // same LDS words for every wave: the whole workgroup leaves together
-        unsigned base = key == 0u ? 0u : key == 1u ? b1 : key == 2u ? b2 : key == 3u ? b3 : key == 4u ? b4
-                      : key == 5u ? b5 : key == 6u ? b6 : key == 7u ? b7 : n_alive;
-        unsigned dst = base + (unsigned)__shfl((int)woff, (int)key) + myrank;
-        if (alive) {
-            sh.st[0][dst] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
-            sh.st[1][dst] = make_float4(s.d.y, s.d.z, s.mask.x, s.mask.y);
-            sh.st[2][dst] = make_float4(s.mask.z, s.L.x, s.L.y, s.L.z);
-            sh.st[3][dst] = make_float4(__uint_as_float(s.seed), __int_as_float(s.bounce), __uint_as_float(s.lp),
-                                        __uint_as_float(s.fl));
-        }
-        __syncthreads();
-        alive = tid < n_alive;  // live paths now occupy slots [0, n_alive), octant by octant
-        if (alive) {
-            const float4 a0 = sh.st[0][tid], a1 = sh.st[1][tid], a2 = sh.st[2][tid], a3 = sh.st[3][tid];
-            s.o = mk3(a0.x, a0.y, a0.z);
-            s.d = mk3(a0.w, a1.x, a1.y);
-            s.mask = mk3(a1.z, a1.w, a2.x);
-            s.L = mk3(a2.y, a2.z, a2.w);
-            s.seed = __float_as_uint(a3.x);
-            s.bounce = __float_as_int(a3.y);
-            s.lp = __float_as_uint(a3.z);
-            s.fl = __float_as_uint(a3.w);
-        }
-        if (__ballot(alive) == 0ull) continue;  // a fully dead wave only takes part in the sort
-        PT_STAMP(t2);
-
-        // ---- intersectWorld with the wave-uniform cull skip -----------------------------------
-        float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
-        int hidx = -1;
-        if (ntri > 0) {
-            PtTriRec a = pt_load_tri(T, 0);
-            int i = 0;
-            for (; i + 1 < ntri; i += 2) {
-                PtTriRec b = pt_load_tri(T, i + 1);
-                bool f0 = pt_tri_test_cull<DET_BOUNDED>(a, i, s.o, s.d, alive, tmax, hu, hv, hidx);
-                a = pt_load_tri(T, i + 2 < ntri ? i + 2 : i + 1);
-                bool f1 = pt_tri_test_cull<DET_BOUNDED>(b, i + 1, s.o, s.d, alive, tmax, hu, hv, hidx);
-#if PT_STAMPS
-                c_full += (f0 ? 1 : 0) + (f1 ? 1 : 0);
-#else
-                (void)f0; (void)f1;
-#endif
-            }
-            if (i < ntri) pt_tri_test_cull<DET_BOUNDED>(a, i, s.o, s.d, alive, tmax, hu, hv, hidx);
-        }
-        PT_STAMP(t3);
-        if (alive) pt_shade<DET_BOUNDED, false>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
-#if PT_STAMPS
-        PT_STAMP(t4);
-        c_regen += t1 - t0; c_sort += t2 - t1; c_loop += t3 - t2; c_shade += t4 - t3; c_iters++;
-#endif
-    }
-#if PT_STAMPS
-    if (P.stats && lane == 0) {
-        atomicAdd(&P.stats[2], c_regen);
-        atomicAdd(&P.stats[3], c_loop);
-        atomicAdd(&P.stats[4], c_shade);
-        atomicAdd(&P.stats[5], c_iters);
-        atomicAdd(&P.stats[6], c_sort);
-        atomicAdd(&P.stats[7], c_full);
-    }
-#endif
-    pt_flush_counters(P, lane, n_rays, n_samples);
+    pt_trace_body<DET_BOUNDED, false, PT_ACCEL_BVH, TALLY>(P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1504,25 +1125,23 @@ hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, 
     return hipGetLastError();
 }
 
-hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool sorted, bool bvh, hipStream_t s)
+hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s)
 {
-    if (bvh && !sorted) {
+    if (bvh) {
         const size_t lds = ptk_trace_lds_bytes(PT_LDS_TRI_MAX + 1);  // camera slots only
-        if (det_bounded) hipLaunchKernelGGL(pt_trace_bvh_kernel<true>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else hipLaunchKernelGGL(pt_trace_bvh_kernel<false>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (tally) {
+            if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        } else {
+            if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        }
         return hipGetLastError();
     }
-    if (sorted) {
-        if (det_bounded) hipLaunchKernelGGL(pt_trace_sorted_kernel<true>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
-        else hipLaunchKernelGGL(pt_trace_sorted_kernel<false>, dim3(num_blocks), dim3(PT_SORT_THREADS), 0, s, p);
-    } else if (p.ntri <= PT_LDS_TRI_MAX && PT_TWO_PASS) {
+    if (p.ntri <= PT_LDS_TRI_MAX) {
         const size_t lds = ptk_trace_lds_bytes(p.ntri);
-        if (det_bounded && quads == 3 && PT_QUAD_PAIRS)
+        if (det_bounded && quads == 3)
             hipLaunchKernelGGL((pt_trace_kernel<true, true, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else if (det_bounded && quads == 2 && PT_QUAD_PAIRS)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, 2>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else if (det_bounded && quads == 1 && PT_QUAD_PAIRS)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, 1>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else if (det_bounded)
             hipLaunchKernelGGL((pt_trace_kernel<true, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else
@@ -1579,11 +1198,10 @@ size_t ptk_trace_lds_bytes(int ntri)
     return table + (size_t)(PT_TRACE_THREADS / 64) * PT_TRACE_BATCH * sizeof(float4);
 }
 
-int ptk_trace_blocks_per_cu(bool sorted, int ntri)
+int ptk_trace_blocks_per_cu(int ntri)
 {
     int nb = 0;
-    hipError_t e = sorted ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_sorted_kernel<true>, PT_SORT_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
-    if (e != hipSuccess || nb < 1) nb = sorted ? 1 : 2;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
+    if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

@@ -62,6 +62,9 @@ struct pt_buffer_s {
     void* staging;      // pinned host range of the last map (kept until the buffer dies)
     size_t staging_bytes;
     bool mapped;
+    size_t mapped_bytes;  // size of the range handed out by the last pt_buffer_map (what unmap copies back)
+    bool exposed;       // the raw device pointer has been handed out (pt_buffer_device_ptr): the caller may
+                        // read or write the memory behind the shim's back, like wrapped memory
 };
 
 struct pt_event_s {
@@ -83,7 +86,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -92,8 +95,8 @@ struct pt_device_s {
     uint64_t prep_version;
     int prep_ntri;
     bool prep_det_bounded;      // scene extent allows the short exact reciprocal
-    int prep_quads;             // 0: no pair structure; 1: every pair (2k, 2k+1) has e2' == -e2;
-                                // 2: additionally p1' == p3, finite radius, margins prepared
+    int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
+                                // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
     PtBvhNode* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
     bool bvh_valid;
@@ -104,7 +107,7 @@ struct pt_device_s {
     float4* rad;
     size_t rad_bytes;
     unsigned int* counters;  // PT_MAX_CHUNKS batch counters
-    int blocks_per_cu, blocks_per_cu_sorted;
+    int blocks_per_cu;
     PendingFrames pending;
     // per-kernel timing (pt_profile_*)
     bool prof_on;
@@ -213,8 +216,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
     }
-    d->blocks_per_cu = ptk_trace_blocks_per_cu(false, 36);
-    d->blocks_per_cu_sorted = ptk_trace_blocks_per_cu(true, 36);
+    d->blocks_per_cu = ptk_trace_blocks_per_cu(36);
     d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
     *out = d;
     return PT_OK;
@@ -283,6 +285,8 @@ extern "C" int pt_device_set_stream(pt_device_t d, void* hip_stream)
     rc = flush_pending(d);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));  // keep the one-queue ordering across the switch
+    // NULL restores the handle's own (non-blocking) stream.  The legacy default stream -- what a
+    // caller's "stream 0" means -- is named by HIP's own sentinel hipStreamLegacy = PT_STREAM_LEGACY.
     d->stream = hip_stream ? (hipStream_t)hip_stream : d->own_stream;
     return PT_OK;
 }
@@ -293,6 +297,13 @@ extern "C" int pt_sync(pt_device_t d)
 {
     int rc = use_device(d);
     if (rc) return rc;
+    // Deferred frames (PT_OPT_BATCH_FRAMES) touch shim-owned, never-exposed buffers only
+    // (launch_generate_colors), which can be observed through this ABI alone: every such
+    // observation flushes.  Should a pending buffer have been exposed since (pt_buffer_device_ptr
+    // flushes, so this is belt and braces), clFinish semantics are restored here.
+    if (d->pending.active && (d->pending.tris->exposed || d->pending.mats->exposed || d->pending.fb->exposed) &&
+        (rc = flush_pending(d)))
+        return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
     return PT_OK;
 }
@@ -321,16 +332,19 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
         d->opt_profile = value ? 1 : 0;
         return PT_OK;
     case PT_OPT_TRACE_VARIANT:
-        if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "trace variant must be 0 (auto), 1 or 2");
+        if (value < 0 || value > 1) return fail(PT_ERR_INVALID, "trace variant must be 0 (auto) or 1 (lane-regenerating waves)");
         d->opt_variant = value;
         return PT_OK;
     case PT_OPT_QUAD_FILTER:
-        if (value < 0 || value > 4) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1 (off), 2 (pairs), 3 (shared u) or 4 (packed shared u)");
+        if (value < 0 || value > 4) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1..3 (independent triangles) or 4 (packed shared u)");
         d->opt_quads = value;
         return PT_OK;
     case PT_OPT_ACCEL:
         if (value < 0 || value > 2) return fail(PT_ERR_INVALID, "accel must be 0 (auto), 1 (brute force) or 2 (BVH)");
         d->opt_accel = value;
+        return PT_OK;
+    case PT_OPT_BVH_TALLY:
+        d->opt_tally = value ? 1 : 0;
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
@@ -346,6 +360,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_TRACE_VARIANT: return d->opt_variant;
     case PT_OPT_QUAD_FILTER: return d->opt_quads;
     case PT_OPT_ACCEL: return d->opt_accel;
+    case PT_OPT_BVH_TALLY: return d->opt_tally;
     default: return -1;
     }
 }
@@ -420,7 +435,20 @@ extern "C" int pt_buffer_free(pt_buffer_t b)
 }
 
 extern "C" size_t pt_buffer_size(pt_buffer_t b) { return b ? b->bytes : 0; }
-extern "C" void* pt_buffer_device_ptr(pt_buffer_t b) { return b ? b->dptr : nullptr; }
+extern "C" void* pt_buffer_device_ptr(pt_buffer_t b)
+{
+    if (!b) return nullptr;
+    // From here on the caller can observe (or change) the memory without going through this ABI:
+    // submit what is deferred now and never defer launches on this buffer again.
+    if (!b->exposed) {
+        b->exposed = true;
+        pt_device_s* d = b->dev;
+        if (d->pending.active && (d->pending.tris == b || d->pending.mats == b || d->pending.fb == b) &&
+            (use_device(d) || flush_pending(d)))
+            return nullptr;
+    }
+    return b->dptr;
+}
 
 static int check_range(const pt_buffer_s* b, size_t off, size_t bytes, const char* what)
 {
@@ -534,6 +562,7 @@ extern "C" void* pt_buffer_map(pt_buffer_t b, size_t bytes, int blocking)
         if (e != hipSuccess) { fail(PT_ERR_HIP, "map sync failed: %s", hipGetErrorString(e)); return nullptr; }
     }
     b->mapped = true;
+    b->mapped_bytes = bytes;
     return b->staging;
 }
 
@@ -544,7 +573,9 @@ extern "C" int pt_buffer_unmap(pt_buffer_t b, void* host_ptr)
     pt_device_s* d = b->dev;
     int rc;
     if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
-    size_t bytes = std::min(b->staging_bytes, b->bytes);
+    // exactly the range pt_buffer_map handed out: the staging allocation is kept at its largest size
+    // ever, and whatever lies beyond this map's range is a stale snapshot
+    size_t bytes = std::min(b->mapped_bytes, b->bytes);
     if (bytes) HIP_TRY(hipMemcpyAsync(b->dptr, b->staging, bytes, hipMemcpyHostToDevice, d->stream));
     b->mapped = false;
     b->version++;
@@ -661,10 +692,11 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     memcpy(&bound, &words[0], sizeof bound);
     memcpy(&radius, &words[2], sizeof radius);
     d->prep_det_bounded = bound <= PT_DET_BOUND_MAX;  // false for NaN / Inf too
-    d->prep_quads = (words[1] == 0u && ntri > 0 && (ntri & 1) == 0) ? 1 : 0;
+    const bool pairs = words[1] == 0u && ntri > 0 && (ntri & 1) == 0;  // every (2k, 2k+1) has e2' == -e2
+    d->prep_quads = 0;
     d->prep_delta1 = 0.0f;
     d->prep_ray_radius = 0.0f;
-    if (d->prep_quads == 1 && d->prep_det_bounded && words[3] == 0u && radius <= 1.0e15f) {
+    if (pairs && d->prep_det_bounded && words[3] == 0u && radius <= 1.0e15f) {
         // quad mode 2: secondary rays start 0.01 off a surface (GenerateColors.cl:253), so their
         // origins stay within ray_radius of the eye; D bounds every coordinate difference between
         // two points of that box; delta1 = 128 u D^2 (derivation: pt_quad2_pass1)
@@ -680,7 +712,7 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->prep_p1_lo = -deltaP;
         d->prep_p1_hi = (delta1 + deltaP) * 1.001f;
     }
-    d->blocks_per_cu = ptk_trace_blocks_per_cu(false, ntri);  // the LDS footprint follows the scene
+    d->blocks_per_cu = ptk_trace_blocks_per_cu(ntri);  // the LDS footprint follows the scene
     d->bvh_valid = false;
     d->prep_src = tris;
     d->prep_version = tris->version;
@@ -746,7 +778,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     if (npix == 0 || rp.frame_count == 0) return event_end(d, ev);
     if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
     // PT_OPT_ACCEL: 0 = BVH for scenes of PT_BVH_AUTO_MIN triangles or more, 1 = brute force, 2 = BVH (needs >= 2 triangles)
-    const bool use_bvh = d->opt_variant != 2 && rp.num_triangles >= 2 &&
+    const bool use_bvh = rp.num_triangles >= 2 &&
                          (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
     if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
 
@@ -823,18 +855,17 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
-        // PT_OPT_QUAD_FILTER: 0 = best the scene allows, k = at most mode k-1
-        const int quads = d->opt_quads ? std::min(d->prep_quads, (int)d->opt_quads - 1) : d->prep_quads;
+        // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
+        const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
         // persistent grid: fill the chip, but never more waves than batches
-        const bool sorted = d->opt_variant == 2 || (d->opt_variant == 0 && PT_DEFAULT_SORTED);
-        const int wg_waves = (sorted ? PT_SORT_THREADS : PT_TRACE_THREADS) / 64;
+        const int wg_waves = PT_TRACE_THREADS / 64;
         uint64_t waves_needed = total_batches;
-        int blocks = d->prop.multiProcessorCount * (sorted ? d->blocks_per_cu_sorted : d->blocks_per_cu);
+        int blocks = d->prop.multiProcessorCount * d->blocks_per_cu;
         uint64_t blocks_needed = (waves_needed + wg_waves - 1) / wg_waves;
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
         if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, sorted, use_bvh, d->stream));
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, use_bvh, d->opt_tally != 0 && stats != nullptr, d->stream));
         if ((rc = prof_end(d, pstop))) return rc;
         PtFoldParams fp;
         fp.rad = d->rad;
@@ -991,7 +1022,12 @@ static int launch_generate_colors(pt_device_s* d, const pt_launch_arg* a, int na
     if (npix > 0xffffffffLL) return fail(PT_ERR_ARGS, "too many work-items");
     if (m->bytes < sizeof(PtRawMaterial)) return fail(PT_ERR_RANGE, "material buffer too small");
 
-    bool immediate = !d->opt_batch || ev || d->opt_profile;
+    // Deferral is invisible only while every buffer involved can be observed through this ABI alone.
+    // Caller-owned (wrapped) memory, or memory whose device pointer has been handed out, may be read
+    // after launch1D + waitForCompletion (clFinish in the reference) or rewritten before the next
+    // launch: such launches execute at once, in order.
+    const bool observable = !t->owned || !m->owned || !fb->owned || t->exposed || m->exposed || fb->exposed;
+    bool immediate = !d->opt_batch || ev || d->opt_profile || observable;
     PendingFrames& p = d->pending;
     if (p.active && !(p.tris == t && p.mats == m && p.fb == fb && p.width == c[0] && p.height == c[1] &&
                       p.pixel_count == (uint32_t)npix && p.z_begin + p.z_count == c[2] && !immediate)) {

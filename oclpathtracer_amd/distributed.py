@@ -58,6 +58,16 @@ def gather_slabs(local_slab: torch.Tensor, world: int, rank: int, dst: int = 0, 
     backend (nccl on GPUs; gloo in the CPU rehearsal tests)."""
     if world == 1:
         return local_slab.unsqueeze(0)
+    if local_slab.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N-rank path on a box with fewer GPUs than ranks (bench.py --rehearse, the
+        # one-GPU world-2 test): gloo has no device gather, the slabs travel through the host
+        host = gather_slabs(local_slab.cpu(), world, rank, dst, group)
+        if rank != dst:
+            return None
+        if out is None:
+            return host.to(local_slab.device)
+        out.copy_(host)
+        return out
     if rank == dst:
         if out is None:
             out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
@@ -77,9 +87,14 @@ class StripeImage:
         self.width, self.height = int(width), int(height)
         self.plan = StripePlan(height, stripe_rows, world)
         self.cuda = torch.device("cuda", torch.cuda.current_device())
-        # all of this rank's device work goes onto torch's current stream
-        shim.check(shim.load().pt_device_set_stream(dev._h, torch.cuda.current_stream().cuda_stream))
+        # All of this rank's shim work (renders, assembly) runs on ONE dedicated torch stream whose
+        # handle is a real hipStream_t (torch's default stream reports 0, which the shim would read
+        # as "restore your own stream").  Every hand-over between that stream and the stream torch
+        # ops / the collective run on is an event wait (wait_stream), never a host sync.
+        self.stream = torch.cuda.Stream(device=self.cuda)
+        shim.check(shim.load().pt_device_set_stream(dev._h, self.stream.cuda_stream))
         self.local = torch.zeros((self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
+        self.stream.wait_stream(torch.cuda.current_stream(self.cuda))  # the zero fill precedes the first render
         self.renderer = Renderer(dev, triangles, materials, width, height, n_ranks=world, rank=rank,
                                  stripe_rows=stripe_rows, fb_device_ptr=self.local.data_ptr(), want_stats=want_stats)
         assert self.renderer.local_rows == self.plan.local_rows(rank)
@@ -96,18 +111,33 @@ class StripeImage:
             self._ibuf.setRawPtr(dev, self.image.data_ptr(), self.image.numel() // 4)
 
     def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> None:
+        """Enqueue frames on the shim stream.  ``self.local`` may be consumed by torch ops on the
+        current stream after ``ready()`` (or ``gather()``), without a host synchronisation."""
+        # torch work already queued on the current stream that touches self.local (a previous
+        # gather reading it, a user op) must finish before the render overwrites it
+        self.stream.wait_stream(torch.cuda.current_stream(self.cuda))
         self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces)
+
+    def ready(self) -> torch.Tensor:
+        """Order torch's current stream after everything enqueued on the shim stream so far and
+        return the local framebuffer tensor (device-side wait only)."""
+        torch.cuda.current_stream(self.cuda).wait_stream(self.stream)
+        return self.local
 
     def gather(self) -> Optional[torch.Tensor]:
         """Assemble the full image on rank 0 (returns it there; None elsewhere)."""
+        cur = torch.cuda.current_stream(self.cuda)
+        cur.wait_stream(self.stream)           # renders -> collective / consumer
         if self.world == 1:
             self.image = self.local[: self.height]
             return self.image
         gather_slabs(self.local, self.world, self.rank, out=self._slabs)
         if self.rank != 0:
             return None
+        self.stream.wait_stream(cur)           # collective -> assembly kernel (reads _slabs)
         shim.check(shim.load().pt_assemble_stripes(self.dev._h, self._gbuf._h, self._ibuf._h, self.width, self.height,
                                                    self.plan.stripe_rows, self.world, self.plan.slab_rows, None))
+        cur.wait_stream(self.stream)           # assembly -> whoever consumes self.image
         return self.image
 
     def reset_stats(self) -> None:
@@ -124,3 +154,5 @@ class StripeImage:
                 b.release()
         self._gbuf = self._ibuf = None
         self.renderer.release()
+        # hand the device handle back to its own stream before the torch stream can die
+        shim.check(shim.load().pt_device_set_stream(self.dev._h, None))

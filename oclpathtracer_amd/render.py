@@ -120,12 +120,17 @@ class Renderer:
         self.dev.waitForCompletion()
         return out
 
-    def read_stats(self) -> dict:
+    def read_stats_raw(self) -> np.ndarray:
+        """All PT_STAT_WORDS work counters (uint64), as accumulated since the buffer was last zeroed."""
         if self.stats is None:
             raise ValueError("renderer was created without want_stats")
         out = np.zeros(shim.PT_STAT_WORDS, np.uint64)
         self.stats.read(out, shim.PT_STAT_WORDS)
         self.dev.waitForCompletion()
+        return out
+
+    def read_stats(self) -> dict:
+        out = self.read_stats_raw()
         return {"samples": int(out[shim.PT_STAT_SAMPLES]), "rays": int(out[shim.PT_STAT_RAYS])}
 
     def global_rows(self) -> np.ndarray:

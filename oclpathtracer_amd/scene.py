@@ -175,13 +175,20 @@ def load_model(path: str | None = None, materials=None):
 
 
 def _splitmix64(n: int, seed: int) -> np.ndarray:
-    """n successive splitmix64 outputs (vectorised)."""
+    """n successive splitmix64 outputs (vectorised, two buffers reused in place: fresh pages are
+    what costs time on a 10^7-element array)."""
     with np.errstate(over="ignore"):
-        i = np.arange(1, n + 1, dtype=np.uint64)
-        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return z ^ (z >> np.uint64(31))
+        z = np.arange(1, n + 1, dtype=np.uint64)
+        z *= np.uint64(0x9E3779B97F4A7C15)
+        z += np.uint64(seed)
+        t = np.empty_like(z)
+        for shift, mul in ((30, 0xBF58476D1CE4E5B9), (27, 0x94D049BB133111EB)):
+            np.right_shift(z, np.uint64(shift), out=t)
+            z ^= t
+            z *= np.uint64(mul)
+        np.right_shift(z, np.uint64(31), out=t)
+        z ^= t
+        return z
 
 
 def make_soup(ntri: int = 1_000_000, seed: int = 20261004, path: str | None = None):

@@ -35,6 +35,10 @@ def cornell():
 @pytest.fixture(scope="session")
 def device():
     """One HIP shim device for the whole GPU session (fails loudly without a GPU)."""
+    try:
+        import torch  # noqa: F401  (first: tests that hand torch tensors to the shim need ONE HIP runtime in the process)
+    except ImportError:
+        pass
     from oclpathtracer_amd import adl
 
     assert adl.init(adl.TYPE_HIP), "adl.init failed: no usable MI355X / libptshim.so"

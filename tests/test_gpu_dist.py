@@ -1,0 +1,141 @@
+"""GPU tests of the N-rank path: one process per rank, image stripes with GLOBAL pixel ids,
+gather to rank 0, device-side assembly -- and of the stream hand-over between the shim and torch.
+
+* ``test_stripe_image_is_ordered_against_torch_without_host_sync`` (1 GPU): results are consumed by torch ops
+  with no host synchronisation in between (what a collective does).
+* ``test_world2_processes_share_one_gpu_gloo`` (1 GPU): two rank PROCESSES on the same MI355X, the product's
+  StripeImage in each, the slabs gathered over gloo through the host (``gather_slabs``' rehearsal branch),
+  assembled by ``pt_assemble_stripes`` on rank 0 -- everything of the N-rank path except RCCL itself.
+* ``test_world2_nccl`` (needs >= 2 devices, skips otherwise): the same with backend nccl (= RCCL) over xGMI.
+* ``test_bench_starts_its_own_ranks`` (1 GPU): ``python bench.py --gpus 2 --rehearse`` with no launcher
+  environment starts two ranks itself and prints rank 0's JSON line.
+All compare with the one-process image bit for bit.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_fb_equal
+
+pytestmark = pytest.mark.gpu
+
+W, H, FRAMES, STRIPE = 256, 192, 6, 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single_gpu_image(device, cornell):
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    r = Renderer(device, tris, mats, W, H)
+    try:
+        r.render(FRAMES)
+        return r.read()
+    finally:
+        r.release()
+
+
+def test_stripe_image_is_ordered_against_torch_without_host_sync(device, cornell):
+    """StripeImage runs the shim on its own torch stream; ``ready()`` / ``gather()`` make torch's current stream
+    wait for it with an event.  A heavy render (1024x1024 x 32 frames, ~5 ms of GPU time) is consumed by a torch
+    op enqueued immediately after, and overwritten by the next render right after that: without the two
+    waits the copy would read a half-written framebuffer (or the second render would clobber it early)."""
+    import torch
+
+    from oclpathtracer_amd.distributed import StripeImage
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    w = h = 1024
+    r = Renderer(device, tris, mats, w, h)
+    try:
+        r.render(32)
+        want32 = r.read()
+        r.render(32, frame_begin=32)
+        want64 = r.read()
+    finally:
+        r.release()
+    img = StripeImage(device, tris, mats, w, h)
+    try:
+        img.render(32, frame_begin=0)
+        snap32 = img.ready().clone()           # torch op on the current stream, no host sync before it
+        img.render(32, frame_begin=32)          # must not overwrite .local before the clone has read it
+        snap64 = img.gather().clone()
+        torch.cuda.synchronize()
+        assert_fb_equal(snap32.cpu().numpy().reshape(-1, 4), want32, "first 32 frames via torch, no host sync")
+        assert_fb_equal(snap64.cpu().numpy().reshape(-1, 4), want64, "64 frames via torch, no host sync")
+    finally:
+        img.release()
+
+
+def _run_world(world, backend, tmp_path, ndev_needed):
+    port = _free_port()
+    out = str(tmp_path / "image.npy")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), backend, out,
+                                       str(W), str(H), str(FRAMES), str(STRIPE)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode("utf-8", "replace"))
+    for rank, (p, log) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, log[-3000:])
+    return np.load(out)
+
+
+def test_world2_processes_share_one_gpu_gloo(device, cornell, tmp_path):
+    want = _single_gpu_image(device, cornell)
+    got = _run_world(2, "gloo", tmp_path, 1)
+    assert_fb_equal(got.reshape(-1, 4), want, "world-2 (gloo through the host) vs one process")
+
+
+def test_world2_nccl(device, cornell, tmp_path):
+    from oclpathtracer_amd import shim
+
+    if shim.load().pt_device_count() < 2:
+        pytest.skip("needs two MI355X: RCCL refuses two ranks on one device")
+    want = _single_gpu_image(device, cornell)
+    got = _run_world(2, "nccl", tmp_path, 2)
+    assert_fb_equal(got.reshape(-1, 4), want, "world-2 (RCCL gather) vs one process")
+
+
+def test_bench_starts_its_own_ranks(device):
+    """`python bench.py --gpus 2` without a launcher environment must start its ranks itself (round-1 review:
+    it used to exit).  On a one-GPU box the two ranks share the device (--rehearse: gloo gather through the
+    host, flagged in the line as not a measurement); with two devices it is the real thing."""
+    from oclpathtracer_amd import shim
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "256", "--height", "256", "--spp", "8"]
+    if shim.load().pt_device_count() < 2:
+        cmd.append("--rehearse")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["rays_per_sample"] > 1.0

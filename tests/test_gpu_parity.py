@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4  # BASELINE.json north_star: "pixels within 1e-4 RMS of the OpenCL reference"
 
 
-VARIANTS = [1, 2]  # PT_OPT_TRACE_VARIANT: lane-regenerating waves / octant-sorted workgroups
+VARIANTS = [1]  # PT_OPT_TRACE_VARIANT: lane-regenerating waves (the octant-sorted experiment of round 1 is gone)
 
 
 def _render_gpu(device, tris, mats, W, H, frames, *, depth=16, frame_begin=0, fb_init=None, variant=0, **kw):
@@ -299,9 +299,10 @@ def _variant_scene(kind):
 @pytest.mark.parametrize("kind", ["quads_scaled", "pairs_broken", "odd_count", "huge_extent", "one_triangle", "degenerate",
                                   "quads_skewed", "quads_tiny", "quads_detached", "quads_nan_second", "quads_far",
                                   "quads_17", "quads_2", "quads_72tri"])
-@pytest.mark.parametrize("quad_filter", [0, 1, 2, 3])
+@pytest.mark.parametrize("quad_filter", [0, 1])
 def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
-    """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows, 1 = none, 2 = pairs, 3 = shared u."""
+    """quad_filter = PT_OPT_QUAD_FILTER: 0 = the strongest pass-1 filter the scene allows (packed shared-u for
+    quad scenes), 1 = independent triangles."""
     from oclpathtracer_amd import shim
 
     tris, mats = _variant_scene(kind)
@@ -376,18 +377,62 @@ def test_bvh_matches_gpu_brute_force_200k_triangles(device):
     assert out[2][1]["rays"] == out[1][1]["rays"]
 
 
+def _erode(mask: np.ndarray) -> np.ndarray:
+    """A block stays only if its 3x3 neighbourhood is all inside the mask (keeps regions off silhouettes)."""
+    m = np.pad(mask, 1, constant_values=False)
+    out = np.ones_like(mask)
+    for dr in (0, 1, 2):
+        for dc in (0, 1, 2):
+            out &= m[dr:dr + mask.shape[0], dc:dc + mask.shape[1]]
+    return out
+
+
+def jpg_regions(ref: np.ndarray) -> dict:
+    """Regions of the reference's rendered image in its 64x64 grid of 8x8-pixel blocks, derived from the
+    committed block fixture itself by colour class and image position, eroded by one block: flat areas inside
+    one surface where a Monte-Carlo + JPEG residual averages out and a SYSTEMATIC restatement error (a biased
+    BRDF lobe, a wrong light radiance, a wrong wall albedo) would not.  Saturated blocks (any channel > 250:
+    the light and its mirror images in the two near-specular GGX boxes, roughness 0.008) are clipped by the
+    8-bit output and carry no signed information; they form their own class and are only checked to stay
+    saturated."""
+    R, G, B = ref[..., 0], ref[..., 1], ref[..., 2]
+    rows = np.arange(ref.shape[0])[:, None] + np.zeros(ref.shape[1], int)[None, :]
+    sat = ref.max(axis=2) >= 250.0
+    green = (R < 12) & (B < 12) & (G >= 60) & ~sat
+    red = (G < 12) & (B < 12) & (R >= 60) & ~sat
+    # the two near-mirror GGX boxes (roughness 0.008) where they reflect the open front of the box: the
+    # path leaves after one specular bounce, the pixel is f2c(sqrt(gamma(0.45 * albedo * 2))) = (213, 196, 126)
+    # with no Monte-Carlo noise at all -- the sharpest pin of the GGX weight f * cos / pdf
+    mirror_bg = (np.abs(R - 213) <= 1.5) & (np.abs(G - 196) <= 1.5) & (np.abs(B - 126) <= 1.5)
+    other = ~(sat | green | red | mirror_bg)
+    regions = {
+        "left wall (green, diffuse)": _erode(green),
+        "right wall (red, diffuse)": _erode(red),
+        "GGX boxes mirroring the background": _erode(mirror_bg),
+        "other unsaturated, rows 0-20 (ceiling)": _erode(other & (rows < 21)),
+        "other unsaturated, rows 21-41": _erode(other & (rows >= 21) & (rows < 42)),
+        "other unsaturated, rows 42-63 (floor, boxes)": _erode(other & (rows >= 42)),
+    }
+    regions = {k: v for k, v in regions.items() if v.sum() >= 4}
+    regions["saturated (clipped by the 8-bit output)"] = _erode(sat)
+    return regions
+
+
 def test_gpu_render_matches_reference_jpg(device, cornell):
-    """The HIP path at the reference's own settings (512x512; 4000 frames of its 10000-frame loop)
-    through the device output stage against the 8x8-pixel block means of the reference's rendered image
-    (tests/golden/reference_jpg_blocks_64x64.npy, from FinalRendered_Specular.jpg): within Monte-Carlo +
-    JPEG noise.  The statistical pin of the whole path against the real OpenCL output."""
-    from oclpathtracer_amd import scene, shim
+    """The HIP path at the reference's own settings -- 512x512, all 10 000 frames of its loop
+    (RaytraceTest.cpp:250) -- through the device output stage f2c(sqrt(.)) (RaytraceTest.cpp:78-83,280-285)
+    against the 8x8-pixel block means of the reference's rendered image
+    (tests/golden/reference_jpg_blocks_64x64.npy, from FinalRendered_Specular.jpg).  The statistical pin of
+    the whole path against the real OpenCL output:
+      * unsigned: mean |difference| over all blocks, worst block, correlation (Monte-Carlo + JPEG noise);
+      * SIGNED mean residual per region (jpg_regions): a systematic error in one surface's shading shows up
+        here long before it moves the unsigned mean; every region must be within REGION_TOL of zero."""
+    from oclpathtracer_amd import scene
     from oclpathtracer_amd.render import Renderer
-    import ctypes
 
     ref = np.load(os.path.join(GOLDEN, "reference_jpg_blocks_64x64.npy")).astype(np.float64)
     tris, mats = cornell
-    W, frames, G = 512, 4000, 64
+    W, frames, G = 512, 10000, 64
     r = Renderer(device, tris, mats, W, W)
     try:
         r.render(frames)
@@ -398,11 +443,33 @@ def test_gpu_render_matches_reference_jpg(device, cornell):
     blocks = img.reshape(G, W // G, G, W // G, 3).mean(axis=(1, 3))
     diff = np.abs(blocks - ref)
     corr = np.corrcoef(blocks.ravel(), ref.ravel())[0, 1]
-    print("gpu vs reference JPG, 64x64 blocks: mean |diff| %.2f max %.1f corr %.5f" % (diff.mean(), diff.max(), corr))
-    # measured: mean |diff| 0.74 of 255, worst block 8.6, correlation 0.99995
+    lines = ["gpu (10000 frames) vs reference JPG, 64x64 blocks: mean |diff| %.3f max %.2f corr %.6f" % (diff.mean(), diff.max(), corr)]
+    worst = 0.0
+    for name, mask in jpg_regions(ref).items():
+        res = (blocks[mask] - ref[mask]).mean(axis=0)
+        lines.append("  %-48s %4d blocks  signed mean residual R %+.3f G %+.3f B %+.3f  (reference level %s)" % (
+            name, int(mask.sum()), res[0], res[1], res[2], np.round(ref[mask].mean(axis=0), 1)))
+        if name.startswith("saturated"):
+            top = ref[mask].argmax(axis=1)   # the channel the reference clips in each of these blocks
+            assert np.take_along_axis(blocks[mask], top[:, None], axis=1).min() > 240.0, "a channel the reference saturates is not saturated here"
+        else:
+            worst = max(worst, float(np.abs(res).max()))
+    report = "\n".join(lines)
+    print(report)
+    out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "jpg_region_residuals.txt"), "w") as f:
+            f.write(report + "\n")
+    except OSError:
+        pass
     assert diff.mean() < 1.5, diff.mean()
     assert diff.max() < 16.0, diff.max()
     assert corr > 0.9998, corr
+    assert worst < REGION_TOL, report
+
+
+REGION_TOL = 1.5  # of 255; see profiles/r02/jpg_region_residuals.txt for the measured values
 
 
 def _random_quad_scene(seed: int):
@@ -463,57 +530,92 @@ def test_random_quad_scenes_match_oracle(device, oracle, seed):
         assert gst["rays"] == st["rays"]
 
 
-def test_configs3_one_rank_of_eight_sampled_pixels(device, cornell, oracle):
-    """BASELINE configs[3] geometry: 2048x2048 dealt to 8 ranks in 16-row stripes; rank 5's share
-    (256 rows, 524 288 pixels) rendered for 8 frames, runs of its pixels recomputed by the oracle
-    from their GLOBAL ids (seed parity across the split, GenerateColors.cl:305-308)."""
+def test_configs3_one_rank_of_eight_full_size(device, cornell, oracle):
+    """BASELINE configs[3] at FULL size for one rank: 2048x2048 dealt to 8 ranks in 16-row stripes; rank 5's
+    share (256 rows, 524 288 pixels) rendered for all 1024 frames (537 M samples), 16 runs of 64 of its
+    pixels recomputed by the oracle through all 1024 frames from their GLOBAL ids (seed parity across
+    the split, GenerateColors.cl:305-308).  Whole-share properties: w == 1, nothing negative, the
+    sample counter equals pixels x frames."""
     from oclpathtracer_amd.render import Renderer
 
     tris, mats = cornell
     W = H = 2048
-    frames, n_ranks, rank, stripe = 8, 8, 5, 16
-    r = Renderer(device, tris, mats, W, H, n_ranks=n_ranks, rank=rank, stripe_rows=stripe)
+    frames, n_ranks, rank, stripe = 1024, 8, 5, 16
+    r = Renderer(device, tris, mats, W, H, n_ranks=n_ranks, rank=rank, stripe_rows=stripe, want_stats=True)
     try:
         r.render(frames)
         got = r.read()
+        st = r.read_stats()
         rows = r.global_rows()
     finally:
         r.release()
     assert len(rows) == H // n_ranks and got.shape == (len(rows) * W, 4)
+    assert st["samples"] == len(rows) * W * frames
     assert np.all(got[:, 3] == 1.0)
+    assert not np.any(got[:, :3] < 0)
     rng = np.random.default_rng(3)
     fb = np.zeros((H * W, 4), np.float32)
-    for lr in rng.integers(0, len(rows), 12):
+    for lr in rng.integers(0, len(rows), 16):
         x0 = int(rng.integers(0, W - 64))
         g0 = int(rows[lr]) * W + x0
         oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=g0, gid_count=64)
         assert_fb_equal(got[lr * W + x0: lr * W + x0 + 64], fb[g0: g0 + 64], "C4 rank %d local row %d" % (rank, lr))
 
 
-def test_configs4_million_triangle_soup(device, oracle):
-    """BASELINE configs[4] scene: the 10^6-triangle soup.  The LBVH render (the default from 512
-    triangles on) against the brute-force kernel (PT_OPT_ACCEL = 1) on a 96x64 image, and both against
-    the CPU oracle on the first 64 pixels: identical bits."""
+def test_configs4_million_triangle_soup_full_size(device, oracle):
+    """BASELINE configs[4] scene at FULL size on one GPU: the 10^6-triangle soup, 1024x1024, 256 spp, depth 16,
+    through the LBVH (the default from 512 triangles on).
+      * whole image: w == 1, nothing negative, sample counter == pixels x frames;
+      * 16 seeded pixels recomputed by the brute-force CPU oracle through all 256 frames (one oracle thread per
+        pixel; ~10^6 exact tests per ray): identical bits;
+      * LBVH against the GPU's own brute-force search (PT_OPT_ACCEL = 1) on the first 64 rows (65 536 pixels),
+        frame 0: identical bits and ray counts."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oclpathtracer_amd import scene, shim
     from oclpathtracer_amd.render import Renderer
 
     tris, mats = scene.make_soup(1_000_000)
-    W, H, frames = 96, 64, 2
+    W = H = 1024
+    frames = 256
+    r = Renderer(device, tris, mats, W, H, want_stats=True)
+    try:
+        r.render(frames)
+        got = r.read()
+        st = r.read_stats()
+    finally:
+        r.release()
+    assert st["samples"] == W * H * frames
+    assert np.all(got[:, 3] == 1.0)
+    assert not np.any(got[:, :3] < 0)
+
+    rng = np.random.default_rng(4)
+    gids = [int(g) for g in rng.integers(0, W * H, 16)]
+
+    def one(gid):
+        fb = np.zeros((H * W, 4), np.float32)
+        oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=gid, gid_count=1, nthreads=1)
+        return fb[gid].copy()
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(one, gids))
+    for gid, w in zip(gids, want):
+        assert_fb_equal(got[gid], w, "1M-triangle soup, LBVH vs oracle, pixel %d" % gid)
+
+    rows_ab = 64
     out = {}
     for accel in (0, 1):
         device.setOption(shim.PT_OPT_ACCEL, accel)
-        r = Renderer(device, tris, mats, W, H, want_stats=True)
+        r = Renderer(device, tris, mats, W, H, n_ranks=H // rows_ab, rank=0, stripe_rows=rows_ab, want_stats=True)
         try:
-            r.render(frames)
+            r.render(1)
             out[accel] = (r.read(), r.read_stats())
         finally:
             r.release()
             device.setOption(shim.PT_OPT_ACCEL, 0)
-    assert_fb_equal(out[0][0], out[1][0], "1M-triangle soup, LBVH vs brute force")
+    assert out[0][0].shape == (rows_ab * W, 4)
+    assert_fb_equal(out[0][0], out[1][0], "1M-triangle soup, LBVH vs brute force, 65 536 pixels")
     assert out[0][1]["rays"] == out[1][1]["rays"]
-    fb = np.zeros((W * H, 4), np.float32)
-    oracle.render(tris, mats, W, H, frames, fb=fb, gid_begin=0, gid_count=64)
-    assert_fb_equal(out[0][0][:64], fb[:64], "1M-triangle soup, LBVH vs oracle")
 
 
 def test_bvh_exact_ties_go_to_the_lowest_index(device, oracle, cornell):

@@ -59,6 +59,100 @@ def test_map_unmap(device):
     b.release()
 
 
+def test_partial_map_writes_back_only_the_mapped_range(device):
+    """Buffer::getHostPtr(size) maps a sub-range (Adl/Adl.inl:247-252).  The pinned staging range is kept
+    at its largest size ever, so a partial unmap must copy back exactly the bytes of ITS map: a full
+    map/unmap, then a change of the buffer on the device, then a partial map/unmap must leave the rest
+    of the device buffer as the device last wrote it (not revert it to the stale staging snapshot)."""
+    from oclpathtracer_amd import adl
+
+    n = 256
+    b = adl.Buffer(device, n, np.int32)
+    first = np.arange(n, dtype=np.int32)
+    p = b.getHostPtr(blocking=True)          # full map: staging now holds n elements
+    p[:] = first
+    b.returnHostPtr(p)
+    second = first * 7 + 3
+    b.write(second, n)                        # the device contents move on behind the staging copy
+    q = b.getHostPtr(16, blocking=True)       # partial map: refreshes 16 elements of the staging range
+    assert q.shape[0] == 16 and np.array_equal(q, second[:16])
+    q[:] = -5
+    b.returnHostPtr(q)
+    back = np.empty(n, np.int32)
+    b.read(back, n)
+    device.waitForCompletion()
+    want = second.copy()
+    want[:16] = -5
+    assert np.array_equal(back, want)
+    b.release()
+
+
+def test_wrapped_buffers_are_never_deferred(device, cornell):
+    """launch1D + waitForCompletion is clFinish in the reference (RaytraceTest.cpp:264-267): memory the
+    caller can reach behind the ABI (a wrapped torch tensor; a buffer whose device pointer was handed
+    out) must hold the frame after the wait, and a scene rewritten between launches must only affect
+    later frames -- so such launches are not batched."""
+    import torch
+
+    from oclpathtracer_amd import adl, shim
+    from oclpathtracer_amd.render import upload_scene
+
+    tris, mats = cornell
+    dim = 32
+    want1 = np.load(os.path.join(GOLDEN, "cornell_64x64_f1_d16.npy"))  # noqa: F841 (shape reference only)
+    lib = shim.load()
+    assert device._lib.pt_device_get_option(device._h, shim.PT_OPT_BATCH_FRAMES) == 1
+
+    def launch(tb, mb, fb, z):
+        launcher = adl.Launcher(device, device.getKernel("../test/ClKernels/GenerateColors", "GenerateColors"))
+        launcher.setBuffers([adl.BufferInfo(tb), adl.BufferInfo(mb), adl.BufferInfo(fb)], 3)
+        launcher.setConst(np.array([dim, dim, z, 0], np.int32))
+        launcher.launch1D(dim * dim)
+        adl.DeviceUtils.waitForCompletion(device)
+
+    # reference image of frames 0..2 through owned, unexposed buffers (deferred path)
+    tb, mb = upload_scene(device, tris, mats)
+    fb = adl.Buffer(device, dim * dim, adl.float4)
+    for z in range(3):
+        launch(tb, mb, fb, z)
+    ref = np.empty((dim * dim, 4), np.float32)
+    fb.read(ref, dim * dim)
+    device.waitForCompletion()
+
+    # (1) framebuffer = caller-owned torch memory: after each wait the tensor already holds the frame
+    t = torch.zeros((dim * dim, 4), dtype=torch.float32, device="cuda")
+    wfb = adl.Buffer(dtype=adl.float4)
+    wfb.setRawPtr(device, t.data_ptr(), dim * dim)
+    snaps = []
+    for z in range(3):
+        launch(tb, mb, wfb, z)
+        torch.cuda.synchronize()
+        snaps.append(t.cpu().numpy().copy())
+    assert np.array_equal(snaps[2].view(np.uint32), ref.view(np.uint32))
+    assert not np.array_equal(snaps[0], snaps[1])  # frame 0 really was on the device after its wait
+
+    # (2) an owned buffer whose device pointer is handed out mid-stream: pending frames are submitted
+    fb2 = adl.Buffer(device, dim * dim, adl.float4)
+    launch(tb, mb, fb2, 0)
+    launch(tb, mb, fb2, 1)
+    ptr = fb2.m_ptr                       # pt_buffer_device_ptr: flushes, switches batching off for fb2
+    device.waitForCompletion()
+    raw = np.empty((dim * dim, 4), np.float32)
+    assert lib.pt_buffer_read(fb2._h, raw.ctypes.data_as(ctypes.c_void_p), raw.nbytes, 0, None) == 0
+    device.waitForCompletion()
+    launch(tb, mb, fb2, 2)
+    out = torch.empty((dim * dim, 4), dtype=torch.float32, device="cuda")
+    src = adl.Buffer(dtype=adl.float4)
+    src.setRawPtr(device, ptr, dim * dim)
+    dst = adl.Buffer(dtype=adl.float4)
+    dst.setRawPtr(device, out.data_ptr(), dim * dim)
+    dst.write(src, dim * dim)
+    device.waitForCompletion()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    for b in (tb, mb, fb, wfb, fb2, src, dst):
+        b.release()
+
+
 def test_fill_kernel_and_events(device):
     from oclpathtracer_amd import adl
 

@@ -7,13 +7,12 @@ import numpy as np
 from oclpathtracer_amd import adl, scene, shim
 from oclpathtracer_amd.render import Renderer
 args = sys.argv[1:]
-variant = int(args.pop(0)) if args else 1
+variant = 1
 W, H, spp, depth = (int(x) for x in (args[:4] + ["1024", "1024", "64", "16"][len(args[:4]):]))
 quad_filter = int(args[4]) if len(args) > 4 else 0
 assert adl.init()
 dev = adl.DeviceUtils.allocate()
 t, m = scene.load_model()
-dev.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
 dev.setOption(shim.PT_OPT_QUAD_FILTER, quad_filter)
 r = Renderer(dev, t, m, W, H, want_stats=True)
 r.render(spp, max_bounces=depth)
