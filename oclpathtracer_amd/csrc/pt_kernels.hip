@@ -800,89 +800,121 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
     }
 }
 
-// ---- variant 1: lane-regenerating waves, no exchange between lanes -------------------------------
-// (A fully unrolled 36-triangle specialisation was tried and dropped: LLVM hoists the unrolled
-// triangles' temporaries, 127 VGPRs / 4 waves per SIMD, 76.0 ms against 70.2 ms for this loop.)
-// LDS_TABLE: the workgroup keeps a copy of the prepared triangle records (stride 12 dwords:
-// conflict-poor for per-lane ds_read_b128) in dynamic LDS for pass 2; per-lane global loads of a
-// 36-record table saturate the CU's vector-memory address path (3 scattered loads per survivor).
-// ---- regeneration, variant 1: camera rays made in bulk ------------------------------------------
-// A wave retires ~10 of its 64 paths per bounce, so generating their successors' camera rays on the
-// spot (2 RNG draws, 3 normalisations: ~160 VALU) ran at 15 % lane utilisation and cost 11 % of the
-// kernel.  Instead, when a wave takes a batch of PT_TRACE_BATCH samples off the queue it generates
-// ALL their primary rays at once, 64 lanes wide, into its slice of LDS (direction + RNG state,
-// 16 B per sample); a dead lane then restarts with one ds_read_b128.  Which lane runs which
-// sample never affects a sample's result.
-struct PtQueueB {
-    unsigned pix, end, frame, base;  // base: first local pixel of the current batch
+// ---- how lanes get their paths: a per-wave pool of parked paths + FRESH phases --------------------
+// Lane = path.  A wave retires ~10 of its 64 paths per bounce.  Round 1 handed every dead lane the next
+// sample of the wave's range on the spot (camera rays pre-generated 64 wide into LDS), so each bounce
+// mixed ~10 primary rays into 54 incoherent secondary ones and every sample's bounce 0 took a full-price
+// slot of the incoherent main loop.  Now the wave keeps a POOL of up to 64 parked paths in LDS (64 B each):
+//   * dead lanes take parked paths from the pool;
+//   * when lanes are dead and the pool is empty, the wave PARKS all its live paths and starts 64 fresh
+//     samples -- 64 consecutive pixels of its range -- in all 64 lanes at once: camera rays at full lane
+//     width straight into registers, and a bounce 0 whose 64 rays share the origin and are coherent
+//     (pass 2 walks ~the same 3-4 survivors in every lane instead of max-over-lanes 8; a wave usually sees
+//     one material, so the untaken BRDF branch is skipped wave-wide).  The following bounces refill the
+//     ~10 lanes that end per bounce from the pool, which lasts ~5 bounces -- until the next fresh phase.
+// Which lane runs which sample, and in which order, never affects a sample's result.
+#define PT_POOL 64  // parked-path slots per wave (a fresh phase parks at most 64 live paths)
+
+struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, end) of local pixels of `frame`
+    unsigned pix, end, frame;
     bool exhausted;
 };
 
-PTK_DEV void pt_camera_batch(const PtTraceParams& P, unsigned lane, const PtQueueB& q, float4* cam)
+// makes [q.pix, q.end) non-empty, taking the next batch off the global queue (one atomic per batch)
+// when the current one is used up; false when there is nothing left
+PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q)
 {
-    for (unsigned k = 0; k < P.batch; k += 64) {
-        const unsigned lp = q.base + k + lane;
-        if (lp < q.end) {
-            const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
-            unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
-            if (P.n_ranks > 1) {
-                unsigned sl = lr / (unsigned)P.stripe_rows;
-                unsigned within = lr - sl * (unsigned)P.stripe_rows;
-                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
-            }
-            const unsigned gid = grow * (unsigned)P.width + x;
-            const int frame = P.frame_begin + (int)q.frame;
-            uint32_t seed = gid + pt_hash_u32((uint32_t)frame);                        // :308
-            f3 o, d;
-            pt_generate_ray((int)x, (int)grow, P.width, P.height, seed, o, d);         // :310
-            cam[k + lane] = make_float4(d.x, d.y, d.z, __uint_as_float(seed));
-        }
+    if (q.pix != q.end) return true;
+    if (q.exhausted) return false;
+    unsigned b = 0;
+    if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= P.total_batches) { q.exhausted = true; return false; }
+    const unsigned f = b / P.batches_per_frame;
+    const unsigned bi = b - f * P.batches_per_frame;
+    q.frame = f;
+    q.pix = bi * P.batch;
+    const unsigned e = q.pix + P.batch;
+    q.end = e < P.npix_local ? e : P.npix_local;
+    return true;
+}
+
+// pool slot k of a wave: four float4 arrays of PT_POOL entries (conflict-free b128 accesses)
+//   [0] o.xyz d.x   [1] d.yz mask.xy   [2] mask.z L.xyz   [3] seed bounce lp fl
+PTK_DEV void pt_pool_push(float4* pool, unsigned& pool_n, const PtPath& s, bool& alive)
+{
+    const unsigned long long live = __ballot(alive);
+    if (alive) {
+        const unsigned k = pool_n + pt_mbcnt(live);
+        pool[k] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+        pool[PT_POOL + k] = make_float4(s.d.y, s.d.z, s.mask.x, s.mask.y);
+        pool[2 * PT_POOL + k] = make_float4(s.mask.z, s.L.x, s.L.y, s.L.z);
+        pool[3 * PT_POOL + k] = make_float4(__uint_as_float(s.seed), __int_as_float(s.bounce), __uint_as_float(s.lp),
+                                            __uint_as_float(s.fl));
     }
-    // the wave's own LDS writes, read back by other lanes of the same wave: program order suffices
-    // for the hardware (one in-order LDS queue per wave); this keeps the compiler from reordering
+    pool_n += (unsigned)__popcll(live);
+    alive = false;
+}
+
+PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
+{
+    const unsigned long long need = __ballot(!alive);
+    const unsigned n_need = (unsigned)__popcll(need);
+    const unsigned take = n_need < pool_n ? n_need : pool_n;
+    if (take == 0u) return;
+    // the wave's own LDS writes (pt_pool_push), read back by other lanes of the same wave: program order
+    // suffices for the hardware (one in-order LDS queue per wave); this keeps the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned rank = pt_mbcnt(need);
+    if (!alive && rank < take) {
+        const unsigned k = pool_n - 1u - rank;
+        const float4 a0 = pool[k], a1 = pool[PT_POOL + k], a2 = pool[2 * PT_POOL + k], a3 = pool[3 * PT_POOL + k];
+        s.o = mk3(a0.x, a0.y, a0.z);
+        s.d = mk3(a0.w, a1.x, a1.y);
+        s.mask = mk3(a1.z, a1.w, a2.x);
+        s.L = mk3(a2.y, a2.z, a2.w);
+        s.seed = __float_as_uint(a3.x);
+        s.bounce = __float_as_int(a3.y);
+        s.lp = __float_as_uint(a3.z);
+        s.fl = __float_as_uint(a3.w);
+        alive = true;
+    }
+    pool_n -= take;
+    // reads of the slots just released must complete before a later push overwrites them: same in-order queue
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-PTK_DEV void pt_regenerate_bulk(const PtTraceParams& P, unsigned lane, PtQueueB& q, PtPath& s, bool& alive, float4* cam)
+// FRESH phase: every lane is dead (its path parked); the next (up to) 64 samples of the wave's range start
+// in lanes 0.. at bounce 0 -- seed :308, camera ray :310
+PTK_DEV void pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
-    unsigned long long need = __ballot(!alive);
-    while (need != 0ull && !q.exhausted) {
-        if (q.pix == q.end) {
-            // (handing every wave its first batch by grid index instead of an atomic was measured
-            // slower for the full image, 36.7 vs 36.0 ms, and no faster for a 1/8 share)
-            unsigned b = 0;
-            if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= P.total_batches) { q.exhausted = true; break; }
-            unsigned f = b / P.batches_per_frame;
-            unsigned bi = b - f * P.batches_per_frame;
-            q.frame = f;
-            q.pix = q.base = bi * P.batch;
-            unsigned e = q.pix + P.batch;
-            q.end = e < P.npix_local ? e : P.npix_local;
-            pt_camera_batch(P, lane, q, cam);
+    const unsigned avail = q.end - q.pix;
+    const unsigned count = avail < 64u ? avail : 64u;
+    if (lane < count) {
+        const unsigned lp = q.pix + lane;
+        const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+        unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
+        if (P.n_ranks > 1) {
+            const unsigned sl = lr / (unsigned)P.stripe_rows;
+            const unsigned within = lr - sl * (unsigned)P.stripe_rows;
+            grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
         }
-        unsigned n_need = (unsigned)__popcll(need);
-        unsigned avail = q.end - q.pix;
-        unsigned take = n_need < avail ? n_need : avail;
-        unsigned rank = pt_mbcnt(need);
-        if (!alive && rank < take) {
-            s.lp = q.pix + rank;
-            s.fl = q.frame;
-            const float4 c = cam[s.lp - q.base];
-            s.o = mk3(PT_EYE_X, PT_EYE_Y, PT_EYE_Z);
-            s.d = mk3(c.x, c.y, c.z);
-            s.seed = __float_as_uint(c.w);
-            s.mask = mk3(1.0f, 1.0f, 1.0f);
-            s.L = mk3(0.0f, 0.0f, 0.0f);
-            s.bounce = 0;
-            alive = true;
-        }
-        q.pix += take;
-        need = __ballot(!alive);
+        const unsigned gid = grow * (unsigned)P.width + x;
+        const int frame = P.frame_begin + (int)q.frame;
+        s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
+        pt_generate_ray((int)x, (int)grow, P.width, P.height, s.seed, s.o, s.d);      // :310
+        s.mask = mk3(1.0f, 1.0f, 1.0f);
+        s.L = mk3(0.0f, 0.0f, 0.0f);
+        s.bounce = 0;
+        s.lp = lp;
+        s.fl = q.frame;
+        alive = true;
     }
+    q.pix += count;
 }
 
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS, bool TALLY = false>
@@ -899,10 +931,11 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         }
         __syncthreads();
     }
-    // this wave's PT_TRACE_BATCH camera-ray slots, behind the triangle table (ptk_trace_lds_bytes)
-    float4* cam = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * PT_TRACE_BATCH;
+    // this wave's pool of parked paths, behind the triangle table (ptk_trace_lds_bytes)
+    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * (4 * PT_POOL);
+    unsigned pool_n = 0u;                    // parked paths (wave-uniform)
 
-    PtQueueB q = { 0u, 0u, 0u, 0u, false };  // wave-uniform (SGPRs)
+    PtWaveQueue q = { 0u, 0u, 0u, false };   // wave-uniform (SGPRs)
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
@@ -919,7 +952,13 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 
     for (;;) {
         PT_STAMP(t0);
-        pt_regenerate_bulk(P, lane, q, s, alive, cam);
+        if (__ballot(!alive) != 0ull) {
+            if (pool_n == 0u && pt_queue_refill(P, lane, q)) {
+                pt_pool_push(pool, pool_n, s, alive);      // park every live path ...
+                pt_start_fresh(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
+            }
+            pt_pool_pop(pool, pool_n, s, alive);           // dead lanes resume parked paths
+        }
         if (__ballot(alive) == 0ull) break;
         PT_STAMP(t1);
 
@@ -1195,7 +1234,7 @@ hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s)
 size_t ptk_trace_lds_bytes(int ntri)
 {
     const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
-    return table + (size_t)(PT_TRACE_THREADS / 64) * PT_TRACE_BATCH * sizeof(float4);
+    return table + (size_t)(PT_TRACE_THREADS / 64) * PT_POOL * 4 * sizeof(float4);
 }
 
 int ptk_trace_blocks_per_cu(int ntri)

@@ -453,7 +453,11 @@ def test_gpu_render_matches_reference_jpg(device, cornell):
             top = ref[mask].argmax(axis=1)   # the channel the reference clips in each of these blocks
             assert np.take_along_axis(blocks[mask], top[:, None], axis=1).min() > 240.0, "a channel the reference saturates is not saturated here"
         else:
-            worst = max(worst, float(np.abs(res).max()))
+            # the large mixed regions carry the diffuse / GI information and average the JPEG's artefacts out;
+            # flat saturated-colour regions keep a DC quantisation offset of the JPEG's chroma planes
+            # (a channel at 0 cannot ring below 0; a flat (213,196,126) area reconstructs R one level off)
+            tol = 0.25 if name.startswith("other") and mask.sum() >= 100 else REGION_TOL
+            worst = max(worst, float(np.abs(res).max()) / tol)
     report = "\n".join(lines)
     print(report)
     out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
@@ -466,10 +470,10 @@ def test_gpu_render_matches_reference_jpg(device, cornell):
     assert diff.mean() < 1.5, diff.mean()
     assert diff.max() < 16.0, diff.max()
     assert corr > 0.9998, corr
-    assert worst < REGION_TOL, report
+    assert worst < 1.0, report
 
 
-REGION_TOL = 1.5  # of 255; see profiles/r02/jpg_region_residuals.txt for the measured values
+REGION_TOL = 1.25  # of 255; measured: profiles/r02/jpg_region_residuals.txt (<= 0.08 in the large mixed regions, <= 0.94 in flat colour areas)
 
 
 def _random_quad_scene(seed: int):
