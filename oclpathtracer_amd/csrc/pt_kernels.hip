@@ -30,6 +30,10 @@
 
 typedef const __attribute__((address_space(4))) float* pt_const_f32p;  // scalar (SMEM) loads
 
+PTK_DEV unsigned pt_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of m below this lane's position
+PTK_DEV unsigned pt_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+
 // camera position, GenerateColors.cl:265
 #define PT_EYE_X 0.0f
 #define PT_EYE_Y 2.75f
@@ -298,6 +302,83 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
     hidx = ok ? i : hidx;
 }
 
+// ---- pass 2, balanced across lanes: the TAIL ---------------------------------------------------------
+// Survivors per ray: 3.3 on average, 8.3 at the wave's slowest lane -- walking every lane's own survivors
+// to the end ran the exact test at 39 % lane efficiency.  The closest hit is order-free: the winner of the
+// reference's ascending loop with its strict `t < tmax` (:125,:145-151) is argmin (t, index) over the
+// triangles that pass every other test.  So each lane walks its own survivors only while MANY lanes still
+// have one (PT_TAIL_LANES); what is left then -- a few survivors in a few lanes -- is appended as
+// (triangle, ray lane) pairs to a per-wave list in LDS, and the pairs are tested 64 at a time, one pair per
+// lane whoever owns the ray: the ray travels by ds_bpermute, the candidate's key (t bits, index) goes to the
+// ray's slot with one 64-bit ds_min.  At the end of the search a ray whose slot holds a better key than its
+// own walk found re-runs the exact test on that one triangle (same operations on the same operands: the
+// same t, u, v bit for bit).  The list outlives the 32-triangle chunks of a large scene, so a brute-force
+// search over thousands of triangles runs its rare survivors at full lane width too.
+#ifndef PT_TAIL_LANES
+#define PT_TAIL_LANES 24  // own steps continue while more lanes than this still hold a survivor; 0 = never use the tail
+#endif
+#define PT_TAIL_LIST 128u  // list capacity: a round is run as soon as 64 pairs are pending, one append adds <= 64
+
+typedef __attribute__((address_space(3))) unsigned pt_lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long pt_lds_u64;
+struct PtTail {
+    pt_lds_u64* keys;  // [64]  best (t bits << 32 | triangle) the tail found for the ray of each lane; ~0 = none
+    pt_lds_u32* list;  // [PT_TAIL_LIST]  pending pairs: triangle << 6 | ray lane  (ring)
+    unsigned wr, rd;   // wave-uniform ring positions
+};
+
+// the reference's test of one (ray, triangle) pair without the running tmax: passes :100,:109,:117 and 0 < t < 1e20
+template <bool DET_BOUNDED>
+PTK_DEV bool pt_tri_candidate(const PtTriRec& r, const f3& o, const f3& d, float& t_out)
+{
+    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+    float inv_det = DET_BOUNDED ? pt_rcp_fast(det) : 1.0f / det;
+    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+    bool ok = !(det < 1e-8f) & !(u < 0.0f);  // (u > 1 is covered by u + v > 1: see pt_tri_pass2)
+    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
+    ok &= !(v < 0.0f) & !(u + v > 1.0f);
+    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
+    ok &= (tt > 0.0f) & (tt < 1e20f);  // :125 against the initial tmax (:141)
+    t_out = tt;
+    return ok;
+}
+
+PTK_DEV float pt_from_lane(unsigned byte_addr, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_addr, __float_as_int(v)));
+}
+
+// test the first `cnt` (<= 64) pending pairs, one per lane; every lane of the wave takes part (the rays travel by
+// ds_bpermute, which needs their owners' lanes enabled)
+template <bool DET_BOUNDED, bool LDS_TABLE>
+PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrepTriangle* tris, const f3& o, const f3& d)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool act = lane < cnt;
+    const unsigned e = act ? tl.list[(tl.rd + lane) & (PT_TAIL_LIST - 1u)] : 0u;
+    const unsigned ray = e & 63u, tri = e >> 6;
+    const unsigned a = ray << 2;
+    const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
+    const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
+    const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, (int)tri);
+    float t;
+    const bool ok = pt_tri_candidate<DET_BOUNDED>(r, po, pd, t) & act;
+    if (ok) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri;
+        __hip_atomic_fetch_min(tl.keys + ray, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    tl.rd += cnt;
+}
+
 // closest hit over triangles [0, ntri): chunks of 32 triangles, pass 1 then pass 2 per chunk.
 // (Software-pipelining pass 2 -- fetching the next survivor's record during the current test --
 // was measured slower: 64.8 ms against 61.1 ms; the register copies cost more than the LDS latency
@@ -391,8 +472,10 @@ template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx,
                                        float delta1, float ray_radius, pt_const_f32p p1tab, float p1_lo, float p1_hi,
+                                       PtTail tl, unsigned lane,
                                        unsigned long long* vstat = nullptr, unsigned long long* p1_ticks = nullptr)
 {
+    tl.wr = tl.rd = 0u;
 #if PT_STAMPS
     unsigned long long ta = 0, tb = 0;
 #endif
@@ -496,8 +579,9 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         PT_STAMP(tb);
         if (p1_ticks) *p1_ticks += tb - ta;
 #endif
-        // every lane tests its next survivor (index 0 and ok = false once it has none left)
-        for (pt_lanes more = PT_LANES(m != 0u); more != 0ull; more = PT_LANES(m != 0u)) {
+        // own steps: every lane tests its next survivor (index 0 and ok = false once it has none left),
+        // while more than PT_TAIL_LANES lanes still hold one
+        for (pt_lanes more = PT_LANES(m != 0u); (unsigned)__popcll(more) > (unsigned)PT_TAIL_LANES; more = PT_LANES(m != 0u)) {
             ++steps;
             const bool valid = m != 0u;
             unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
@@ -509,11 +593,52 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
             const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
             pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
         }
+        // the rest of this chunk's survivors join the wave's pending pairs
+        if (PT_TAIL_LANES > 0) {
+            for (pt_lanes has = PT_LANES(m != 0u); has != 0ull; has = PT_LANES(m != 0u)) {
+                if (m != 0u) {
+                    unsigned lz;
+                    asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
+                    m &= ~(0x80000000u >> (lz & 31u));
+                    const unsigned tri = (unsigned)(base + n - 32) + lz;
+                    tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = (tri << 6) | lane;
+                }
+                tl.wr += (unsigned)__popcll(has);
+                if (tl.wr - tl.rd >= 64u) {
+                    ++steps;
+                    pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, 64u, lane, tris, o, d);
+                }
+            }
+        }
+    }
+    if (PT_TAIL_LANES > 0) {
+        if (tl.wr != tl.rd) {
+            ++steps;
+            pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, tl.wr - tl.rd, lane, tris, o, d);
+        }
+        if (tl.wr != 0u) {  // (wave-uniform) this search used the tail: merge what it found
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long key = tl.keys[lane];
+            tl.keys[lane] = ~0ull;
+            const float kt = __uint_as_float((unsigned)(key >> 32));
+            const int ki = (int)(unsigned)key;
+            // the reference's winner is the lexicographic minimum of (t, index)
+            const bool better = (key != ~0ull) & ((kt < tmax) | ((kt == tmax) & (ki < hidx)));
+            if (PT_LANES(better) != 0ull) {
+                ++steps;
+                const int i = (LDS_TABLE || better) ? ki : 0;
+                const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+                float tm = better ? 1e20f : tmax;  // (a lane that is not `better` must keep its own result: valid = false)
+                pt_tri_pass2<DET_BOUNDED>(r, i, better, o, d, tm, hu, hv, hidx);
+                tmax = tm;
+            }
+        }
     }
     return steps;
 }
 
-PTK_DEV unsigned pt_lane_id();
 // ---- closest hit through the LBVH (pt_bvh.hip) -----------------------------------------------------
 // Stackless traversal along the nodes' miss links; every lane walks its own ray.  At a leaf the
 // reference's exact test runs with pt_tri_pass2's arithmetic; because leaves are met in tree order,
@@ -652,8 +777,6 @@ struct PtPath {
     unsigned fl;    // frame index inside the chunk
 };
 
-PTK_DEV unsigned pt_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-PTK_DEV unsigned pt_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
 template <bool DET_BOUNDED>
@@ -934,6 +1057,16 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
     // this wave's pool of parked paths, behind the triangle table (ptk_trace_lds_bytes)
     float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * (4 * PT_POOL);
     unsigned pool_n = 0u;                    // parked paths (wave-uniform)
+    // this wave's pass-2 tail: 64 key slots + the pending-pair ring, behind the four pools
+    PtTail tl;
+    {
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0) + (PT_TRACE_THREADS / 64) * (16 * PT_POOL) +
+                        (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
+        tl.keys = (pt_lds_u64*)w;
+        tl.list = w + 128;
+        tl.wr = tl.rd = 0u;
+        tl.keys[lane] = ~0ull;
+    }
 
     PtWaveQueue q = { 0u, 0u, 0u, false };   // wave-uniform (SGPRs)
     bool alive = false;
@@ -971,7 +1104,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         else
             p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
-                                                                                          (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi,
+                                                                                          (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi, tl, lane,
                                                                                           PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr,
 #if PT_STAMPS
                                                                                           &c_p1
@@ -1234,7 +1367,8 @@ hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s)
 size_t ptk_trace_lds_bytes(int ntri)
 {
     const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
-    return table + (size_t)(PT_TRACE_THREADS / 64) * PT_POOL * 4 * sizeof(float4);
+    // per wave: the pool of parked paths (PT_POOL x 64 B) + the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
+    return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL * 4 * sizeof(float4) + 64 * 8 + PT_TAIL_LIST * 4);
 }
 
 int ptk_trace_blocks_per_cu(int ntri)

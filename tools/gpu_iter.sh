@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1
 rc=$?; echo "pytest rc=$rc"; tail -4 gpurun_out/${TAG}_pytest.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench.log 2>&1
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-configs > gpurun_out/${TAG}_bench.log 2>&1
 echo "bench rc=$?"
 python3 - <<PY
 import json
