@@ -125,7 +125,12 @@ enum pt_option {
     /* measurement only (bench.py's roofline of LBVH runs): 1 = renders that pass a stats buffer and
      * take the LBVH use the tallying build of the search, which adds its work counters to
      * stats[PT_STAT_BVH_*].  Same pixels; slower; never the timed kernel.  Default 0. */
-    PT_OPT_BVH_TALLY = 6
+    PT_OPT_BVH_TALLY = 6,
+    /* 1 (default): for quad scenes of up to 64 triangles on the brute-force path, every render first computes,
+     * per pixel, a conservative candidate set of triangles its primary rays can meet (the camera is fixed:
+     * GenerateColors.cl:265-272), and waves of fresh primary rays skip the pass-1 filter.  0 = off (A/B timing,
+     * parity tests).  Identical pixels either way. */
+    PT_OPT_PRIMARY_MASKS = 7
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

@@ -58,6 +58,8 @@ struct PtTraceParams {
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
     const PtBvhNode* bvh;         // accel = BVH: ntri-1 internal nodes, root 0
+    const uint2* pmask;           // quad mode 3, <= 64 triangles: per local pixel the primary rays' candidate masks of the two
+                                  // 32-triangle chunks (pt_primary_mask_kernel); null = run pass 1 for primary rays too
 };
 
 struct PtFoldParams {
@@ -80,6 +82,8 @@ hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int
 hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, float delta1, float* p1tab, hipStream_t s);
 #define PT_P1_STRIDE 24  // floats per quad pair: nx ny nz e2x e2y e2z Kx Ky Kz dhi, each {quad 2p, quad 2p+1}, 4 pad
 static inline size_t ptk_p1tab_floats(int ntri) { return (size_t)((ntri / 2 + 1) / 2) * PT_P1_STRIDE; }
+// fills p.pmask (when not null) for the image geometry of p; needs p.p1tab (quad mode 3)
+hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s);
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
 // quads: 0 = independent triangles (pt_tri_pass1); 3 = ntri is even, every pair (2k, 2k+1) is a quad
 //        (a,b,c),(c,d,a), the margins and the packed table p.p1tab are prepared (pt_quad3_pass1)

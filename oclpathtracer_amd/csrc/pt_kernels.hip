@@ -141,7 +141,8 @@ __global__ void pt_prep_p1tab_kernel(const PtPrepTriangle* __restrict__ tris, in
 // ------------------------------------------------------------------------------------------
 // camera: GenerateColors.cl:73-87, 263-288
 // ------------------------------------------------------------------------------------------
-PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& seed, f3& org, f3& dir_out)
+// the camera ray through image-plane position (x, y), in pixels (GenerateColors.cl:265-287 after the jitter)
+PTK_DEV void pt_camera_ray(float x, float y, int width, int height, f3& org, f3& dir_out)
 {
     float invWidth = 1.0f / (float)width, invHeight = 1.0f / (float)height;
     float aspectratio = (float)width / (float)height;
@@ -154,8 +155,6 @@ PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& se
     const f3 holDir = normalize3(cross3(viewDir, up));
     const f3 upDir = normalize3(cross3(holDir, viewDir));
 
-    float x = (float)xc + pt_random_float(seed) - 0.5f;
-    float y = (float)yc + pt_random_float(seed) - 0.5f;
     x = (2.0f * ((x + 0.5f) * invWidth) - 1.0f) * angle * aspectratio;
     y = -(1.0f - 2.0f * ((y + 0.5f) * invHeight)) * angle;
 
@@ -165,6 +164,81 @@ PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& se
     f3 pointAimed = add3(eye, scale3(dir, 4.0f));
     org = eye;
     dir_out = normalize3(normalize3(sub3(pointAimed, eye)));  // :287 then getRay's own normalize (:75)
+}
+
+PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& seed, f3& org, f3& dir_out)
+{
+    float x = (float)xc + pt_random_float(seed) - 0.5f;  // :278-279: two draws, x first
+    float y = (float)yc + pt_random_float(seed) - 0.5f;
+    pt_camera_ray(x, y, width, height, org, dir_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// primary-ray candidate masks (quad scenes of up to 64 triangles)
+// ------------------------------------------------------------------------------------------
+// The camera is fixed (eye, view direction: GenerateColors.cl:265-272), so what a pixel's primary rays can hit
+// is a property of the pixel: every frame's ray goes through the pixel's footprint, jittered by less than half
+// a pixel (:278-281).  For a primary ray M = (o - eye) x dir = 0 and pass 1's two forms (pt_quad3_pass1) are
+// LINEAR in the direction: un(d) = -K . d, T(d) = n' . d + dhi.  Over the footprint the direction stays within
+// eps of the centre ray's d_c in every component:
+//     the unnormalised direction moves by at most h = |(angle aspect / W, angle / H)|_2 (hol, up orthonormal),
+//     its length is >= 1, and radial projection onto the unit sphere from outside is 1-Lipschitz;
+//     eps = 1.01 h + 4e-6 also covers the rounding of the reference's own ray set-up (three normalisations).
+// Hence |un(d) - un(d_c)| <= eps |K|_1 =: rho_u and |T(d) - T(d_c)| <= eps |n'|_1 =: rho_T for every ray of the
+// pixel, and a (ray, quad) pair pass 1 would keep -- |un| <= T, un >= lo (first triangle), un <= hi (second),
+// each evaluated in binary32 within deltaP of the real value -- has |un(d_c)| <= T(d_c) + rho_u + rho_T + 4 deltaP
+// and the matching one-sided bounds.  One thread per local pixel writes the two 32-bit chunk masks in pass 1's
+// own bit order; a FRESH wave of primary rays then loads its masks instead of running pass 1 (which is a third
+// of a bounce).  Everything downstream (the exact tests of pass 2) is unchanged, so the pixels are too;
+// tools/validate_filter.py counts violations of the cached masks like those of any other filter.
+struct PtMaskParams {
+    const float* p1tab;
+    uint2* out;
+    int32_t width, height, ntri;
+    int32_t stripe_rows, n_ranks, rank;
+    uint32_t npix_local;
+    float p1_lo, p1_hi;
+};
+
+__global__ void pt_primary_mask_kernel(const PtMaskParams P)
+{
+    const unsigned lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= P.npix_local) return;
+    const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+    unsigned grow = lr;
+    if (P.n_ranks > 1) {
+        const unsigned sl = lr / (unsigned)P.stripe_rows;
+        const unsigned within = lr - sl * (unsigned)P.stripe_rows;
+        grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+    }
+    f3 o, dc;
+    pt_camera_ray((float)x, (float)grow, P.width, P.height, o, dc);  // the jitter's midpoint: xi = 0.5
+    const float hx = PTK_TAN_HALF_FOV * ((float)P.width / (float)P.height) / (float)P.width;
+    const float hy = PTK_TAN_HALF_FOV / (float)P.height;
+    const float eps = __builtin_sqrtf(hx * hx + hy * hy) * 1.01f + 4e-6f;
+    const float E = -4.0f * P.p1_lo;  // 4 deltaP
+    const int nquads = P.ntri / 2;
+    unsigned m[2] = { 0u, 0u };
+    for (int q = 0; q < nquads; ++q) {
+        const float* tp = P.p1tab + (size_t)(q >> 1) * PT_P1_STRIDE;  // nx ny nz e2x e2y e2z Kx Ky Kz dhi, {quad 2p, quad 2p+1}
+        const int h = q & 1;
+        const float nx = tp[0 + h], ny = tp[2 + h], nz = tp[4 + h];
+        const float kx = tp[12 + h], ky = tp[14 + h], kz = tp[16 + h];
+        const float dhi = tp[18 + h];
+        const float Tc = pt_fma(dc.z, nz, pt_fma(dc.y, ny, dc.x * nx)) + dhi;
+        const float uc = -pt_fma(dc.z, kz, pt_fma(dc.y, ky, dc.x * kx));
+        const float rho_u = eps * (__builtin_fabsf(kx) + __builtin_fabsf(ky) + __builtin_fabsf(kz)) * 1.001f;
+        const float rho_T = eps * (__builtin_fabsf(nx) + __builtin_fabsf(ny) + __builtin_fabsf(nz)) * 1.001f;
+        // NaNs fail every comparison and are kept, as in pass 1
+        const bool in = !(__builtin_fabsf(uc) > (Tc + rho_u + rho_T + E) * 1.001f);
+        const bool fa = in & !(uc + (rho_u + E) * 1.001f < P.p1_lo);
+        const bool fb = in & !(uc - (rho_u + E) * 1.001f > P.p1_hi);
+        const int j = 2 * q, c = j >> 5;
+        const int nc = P.ntri - 32 * c < 32 ? P.ntri - 32 * c : 32;
+        m[c] |= (fa ? 1u : 0u) << (nc - 1 - (j & 31));
+        m[c] |= (fb ? 1u : 0u) << (nc - 2 - (j & 31));
+    }
+    P.out[lp] = make_uint2(m[0], m[1]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -379,6 +453,76 @@ PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrep
     tl.rd += cnt;
 }
 
+// pass 2 of one 32-triangle chunk whose survivor mask is m (bit n-1-j <-> triangle base + j)
+template <bool DET_BOUNDED, bool LDS_TABLE>
+PTK_DEV void pt_pass2_chunk(unsigned m, int base, int n, const PtPrepTriangle* tris, const f3& o, const f3& d, float& tmax, float& hu,
+                            float& hv, int& hidx, PtTail& tl, unsigned lane, unsigned& steps)
+{
+    // own steps: every lane tests its next survivor (index 0 and ok = false once it has none left),
+    // while more than PT_TAIL_LANES lanes still hold one
+    for (pt_lanes more = PT_LANES(m != 0u); (unsigned)__popcll(more) > (unsigned)PT_TAIL_LANES; more = PT_LANES(m != 0u)) {
+        ++steps;
+        const bool valid = m != 0u;
+        unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
+        asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
+        // (a lane without survivors forms a wild index: harmless for the LDS table -- out-of-range
+        // LDS reads return 0 -- and its result is discarded; the global table needs a real address)
+        const int i = (LDS_TABLE || valid) ? base + n - 32 + (int)lz : base;
+        m &= ~(0x80000000u >> (lz & 31u));
+        const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+        pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
+    }
+    // the rest of this chunk's survivors join the wave's pending pairs
+    if (PT_TAIL_LANES > 0) {
+        for (pt_lanes has = PT_LANES(m != 0u); has != 0ull; has = PT_LANES(m != 0u)) {
+            if (m != 0u) {
+                unsigned lz;
+                asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
+                m &= ~(0x80000000u >> (lz & 31u));
+                const unsigned tri = (unsigned)(base + n - 32) + lz;
+                tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = (tri << 6) | lane;
+            }
+            tl.wr += (unsigned)__popcll(has);
+            if (tl.wr - tl.rd >= 64u) {
+                ++steps;
+                pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, 64u, lane, tris, o, d);
+            }
+        }
+    }
+}
+
+// end of a search: the pending pairs, then the merge of what the tail found
+template <bool DET_BOUNDED, bool LDS_TABLE>
+PTK_DEV void pt_pass2_finish(const PtPrepTriangle* tris, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx,
+                             PtTail& tl, unsigned lane, unsigned& steps)
+{
+    if (PT_TAIL_LANES > 0) {
+        if (tl.wr != tl.rd) {
+            ++steps;
+            pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, tl.wr - tl.rd, lane, tris, o, d);
+        }
+        if (tl.wr != 0u) {  // (wave-uniform) this search used the tail: merge what it found
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long key = tl.keys[lane];
+            tl.keys[lane] = ~0ull;
+            const float kt = __uint_as_float((unsigned)(key >> 32));
+            const int ki = (int)(unsigned)key;
+            // the reference's winner is the lexicographic minimum of (t, index)
+            const bool better = (key != ~0ull) & ((kt < tmax) | ((kt == tmax) & (ki < hidx)));
+            if (PT_LANES(better) != 0ull) {
+                ++steps;
+                const int i = (LDS_TABLE || better) ? ki : 0;
+                const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+                float tm = better ? 1e20f : tmax;  // (a lane that is not `better` must keep its own result: valid = false)
+                pt_tri_pass2<DET_BOUNDED>(r, i, better, o, d, tm, hu, hv, hidx);
+                tmax = tm;
+            }
+        }
+    }
+}
+
 // closest hit over triangles [0, ntri): chunks of 32 triangles, pass 1 then pass 2 per chunk.
 // (Software-pipelining pass 2 -- fetching the next survivor's record during the current test --
 // was measured slower: 64.8 ms against 61.1 ms; the register copies cost more than the LDS latency
@@ -579,63 +723,51 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
         PT_STAMP(tb);
         if (p1_ticks) *p1_ticks += tb - ta;
 #endif
-        // own steps: every lane tests its next survivor (index 0 and ok = false once it has none left),
-        // while more than PT_TAIL_LANES lanes still hold one
-        for (pt_lanes more = PT_LANES(m != 0u); (unsigned)__popcll(more) > (unsigned)PT_TAIL_LANES; more = PT_LANES(m != 0u)) {
-            ++steps;
-            const bool valid = m != 0u;
-            unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
-            asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
-            // (a lane without survivors forms a wild index: harmless for the LDS table -- out-of-range
-            // LDS reads return 0 -- and its result is discarded; the global table needs a real address)
-            const int i = (LDS_TABLE || valid) ? base + n - 32 + (int)lz : base;
-            m &= ~(0x80000000u >> (lz & 31u));
-            const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
-            pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
-        }
-        // the rest of this chunk's survivors join the wave's pending pairs
-        if (PT_TAIL_LANES > 0) {
-            for (pt_lanes has = PT_LANES(m != 0u); has != 0ull; has = PT_LANES(m != 0u)) {
-                if (m != 0u) {
-                    unsigned lz;
-                    asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
-                    m &= ~(0x80000000u >> (lz & 31u));
-                    const unsigned tri = (unsigned)(base + n - 32) + lz;
-                    tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = (tri << 6) | lane;
-                }
-                tl.wr += (unsigned)__popcll(has);
-                if (tl.wr - tl.rd >= 64u) {
-                    ++steps;
-                    pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, 64u, lane, tris, o, d);
-                }
-            }
-        }
+        pt_pass2_chunk<DET_BOUNDED, LDS_TABLE>(m, base, n, tris, o, d, tmax, hu, hv, hidx, tl, lane, steps);
     }
-    if (PT_TAIL_LANES > 0) {
-        if (tl.wr != tl.rd) {
-            ++steps;
-            pt_tail_round<DET_BOUNDED, LDS_TABLE>(tl, tl.wr - tl.rd, lane, tris, o, d);
-        }
-        if (tl.wr != 0u) {  // (wave-uniform) this search used the tail: merge what it found
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const unsigned long long key = tl.keys[lane];
-            tl.keys[lane] = ~0ull;
-            const float kt = __uint_as_float((unsigned)(key >> 32));
-            const int ki = (int)(unsigned)key;
-            // the reference's winner is the lexicographic minimum of (t, index)
-            const bool better = (key != ~0ull) & ((kt < tmax) | ((kt == tmax) & (ki < hidx)));
-            if (PT_LANES(better) != 0ull) {
-                ++steps;
-                const int i = (LDS_TABLE || better) ? ki : 0;
-                const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
-                float tm = better ? 1e20f : tmax;  // (a lane that is not `better` must keep its own result: valid = false)
-                pt_tri_pass2<DET_BOUNDED>(r, i, better, o, d, tm, hu, hv, hidx);
-                tmax = tm;
+    pt_pass2_finish<DET_BOUNDED, LDS_TABLE>(tris, o, d, tmax, hu, hv, hidx, tl, lane, steps);
+    return steps;
+}
+
+// closest hit of a FRESH wave of primary rays whose pixels have candidate masks (pt_primary_mask_kernel):
+// pass 1 is skipped, pass 2 is the one of pt_intersect_two_pass.  ntri <= 64 (two chunks).
+template <bool DET_BOUNDED, bool LDS_TABLE>
+PTK_DEV unsigned pt_intersect_primary(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d, bool alive,
+                                      float& tmax, float& hu, float& hv, int& hidx, uint2 pm, PtTail tl, unsigned lane,
+                                      unsigned long long* vstat = nullptr)
+{
+    (void)T; (void)vstat;
+    tl.wr = tl.rd = 0u;
+    unsigned steps = 0;
+    for (int base = 0; base < ntri; base += 32) {
+        const int n = ntri - base < 32 ? ntri - base : 32;
+        unsigned m = base == 0 ? pm.x : pm.y;
+#if PT_VALIDATE_FILTER
+        if (alive && vstat) {  // the reference predicate of :100 and :109 must never accept a pair the mask dropped
+            unsigned mx = 0u;
+            for (int jj = 0; jj < n; ++jj) {
+                const PtTriRec r = pt_load_tri(T, base + jj);
+                float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
+                float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
+                float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
+                float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+                bool keep = !(det < 1e-8f || -det > 1e-8f);
+                float inv_det = 1.0f / det;
+                float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
+                float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+                keep = keep && !(u < 0.0f || u > 1.0f);
+                mx |= (keep ? 1u : 0u) << (n - 1 - jj);
             }
+            atomicAdd(&vstat[0], (unsigned long long)n);
+            atomicAdd(&vstat[1], (unsigned long long)__popc(mx));
+            atomicAdd(&vstat[2], (unsigned long long)__popc(m));
+            atomicAdd(&vstat[3], (unsigned long long)__popc(mx & ~m));   // VIOLATIONS: must stay 0
         }
+#endif
+        if (!alive) m = 0u;
+        pt_pass2_chunk<DET_BOUNDED, LDS_TABLE>(m, base, n, tris, o, d, tmax, hu, hv, hidx, tl, lane, steps);
     }
+    pt_pass2_finish<DET_BOUNDED, LDS_TABLE>(tris, o, d, tmax, hu, hv, hidx, tl, lane, steps);
     return steps;
 }
 
@@ -1013,7 +1145,8 @@ PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
 
 // FRESH phase: every lane is dead (its path parked); the next (up to) 64 samples of the wave's range start
 // in lanes 0.. at bounce 0 -- seed :308, camera ray :310
-PTK_DEV void pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
+// returns true when all 64 lanes started a primary ray
+PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
     const unsigned avail = q.end - q.pix;
     const unsigned count = avail < 64u ? avail : 64u;
@@ -1038,6 +1171,7 @@ PTK_DEV void pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
         alive = true;
     }
     q.pix += count;
+    return count == 64u;
 }
 
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS, bool TALLY = false>
@@ -1085,10 +1219,11 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 
     for (;;) {
         PT_STAMP(t0);
+        bool primary = false;   // (wave-uniform) this bounce is a fresh wave of 64 primary rays
         if (__ballot(!alive) != 0ull) {
             if (pool_n == 0u && pt_queue_refill(P, lane, q)) {
-                pt_pool_push(pool, pool_n, s, alive);      // park every live path ...
-                pt_start_fresh(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
+                pt_pool_push(pool, pool_n, s, alive);                // park every live path ...
+                primary = pt_start_fresh(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
             }
             pt_pool_pop(pool, pool_n, s, alive);           // dead lanes resume parked paths
         }
@@ -1101,6 +1236,9 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         unsigned p2steps = 0;
         if (QUADS == PT_ACCEL_BVH)
             pt_intersect_bvh<DET_BOUNDED, TALLY>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.stats ? P.stats + 2 : nullptr);
+        else if (QUADS == 3 && DET_BOUNDED && primary && P.pmask != nullptr)
+            p2steps = pt_intersect_primary<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.pmask[s.lp], tl, lane,
+                                                                   PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr);
         else
             p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
@@ -1153,8 +1291,11 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 // (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
 // makes hipcc keep 94 SGPRs (a few spilled to VGPR lanes): 60.9 -> 59.8 ms when introduced; 8 waves
 // (64 VGPRs, 78 SGPRs, 10 + 28 spills) is slower again: 38.2 vs 36.8 ms.
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 7
+#endif
 template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
-__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
 void pt_trace_kernel(const PtTraceParams P)
 {
     pt_trace_body<DET_BOUNDED, LDS_TABLE, QUADS>(P);
@@ -1294,6 +1435,20 @@ hipError_t ptk_prep_quad_margins(PtPrepTriangle* out, int ntri, float diameter, 
         const int qpairs = (pairs + 1) / 2;
         hipLaunchKernelGGL(pt_prep_p1tab_kernel, dim3((qpairs + 255) / 256), dim3(256), 0, s, out, ntri, diameter, p1tab);
     }
+    return hipGetLastError();
+}
+
+hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s)
+{
+    if (!p.pmask || p.npix_local == 0) return hipSuccess;
+    PtMaskParams m;
+    m.p1tab = p.p1tab;
+    m.out = const_cast<uint2*>(p.pmask);
+    m.width = p.width; m.height = p.height; m.ntri = p.ntri;
+    m.stripe_rows = p.stripe_rows; m.n_ranks = p.n_ranks; m.rank = p.rank;
+    m.npix_local = p.npix_local;
+    m.p1_lo = p.p1_lo; m.p1_hi = p.p1_hi;
+    hipLaunchKernelGGL(pt_primary_mask_kernel, dim3((p.npix_local + 255u) / 256u), dim3(256), 0, s, m);
     return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally, opt_pmask;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -106,6 +106,8 @@ struct pt_device_s {
     // fused-render workspace
     float4* rad;
     size_t rad_bytes;
+    uint2* pmask;            // primary-ray candidate masks of the local pixels (pt_primary_mask_kernel)
+    size_t pmask_pixels;
     unsigned int* counters;  // PT_MAX_CHUNKS batch counters
     int blocks_per_cu;
     PendingFrames pending;
@@ -139,6 +141,9 @@ static int prof_end(pt_device_s* d, hipEvent_t stop)
 }
 
 #define PT_MAX_CHUNKS 4096
+#ifndef PT_DEFAULT_PRIMARY_MASKS
+#define PT_DEFAULT_PRIMARY_MASKS 1  // PT_OPT_PRIMARY_MASKS of a new device handle (A/B builds set 0)
+#endif
 
 static int g_init_count = 0;
 
@@ -207,6 +212,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_variant = 0;
     d->opt_quads = 0;
     d->opt_accel = 0;
+    d->opt_pmask = PT_DEFAULT_PRIMARY_MASKS;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
@@ -236,6 +242,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->p1tab) hipFree(d->p1tab);
     if (d->bvh) hipFree(d->bvh);
     if (d->rad) hipFree(d->rad);
+    if (d->pmask) hipFree(d->pmask);
     if (d->counters) hipFree(d->counters);
     if (d->det_bound_dev) hipFree(d->det_bound_dev);
     for (int k = 0; k < PT_PROF_KINDS; ++k)
@@ -346,6 +353,9 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
     case PT_OPT_BVH_TALLY:
         d->opt_tally = value ? 1 : 0;
         return PT_OK;
+    case PT_OPT_PRIMARY_MASKS:
+        d->opt_pmask = value ? 1 : 0;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -361,6 +371,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_QUAD_FILTER: return d->opt_quads;
     case PT_OPT_ACCEL: return d->opt_accel;
     case PT_OPT_BVH_TALLY: return d->opt_tally;
+    case PT_OPT_PRIMARY_MASKS: return d->opt_pmask;
     default: return -1;
     }
 }
@@ -812,6 +823,18 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         d->rad_bytes = need;
     }
     HIP_TRY(hipMemsetAsync(d->counters, 0, (size_t)nchunks * sizeof(unsigned int), d->stream));
+    // primary-ray candidate masks: quad scenes of up to 64 triangles on the brute-force path (PT_OPT_PRIMARY_MASKS)
+    const int quads_sel = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
+    const bool use_pmask = d->opt_pmask && quads_sel == 3 && !use_bvh && rp.num_triangles <= 64 && d->prep_det_bounded;
+    if (use_pmask && d->pmask_pixels < npix) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        if (d->pmask) hipFree(d->pmask);
+        d->pmask = nullptr;
+        d->pmask_pixels = 0;
+        hipError_t e = hipMalloc(&d->pmask, (size_t)npix * sizeof(uint2));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "primary-mask allocation (%zu bytes) failed: %s", (size_t)npix * sizeof(uint2), hipGetErrorString(e)); }
+        d->pmask_pixels = npix;
+    }
 
     // Samples per work-queue grab.  A wave that finds the queue empty idles until the last wave is
     // done, on average for half a batch: large batches (fewer atomics) when every wave gets many of
@@ -855,6 +878,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
+        tp.pmask = use_pmask ? d->pmask : nullptr;
+        if (c == 0 && use_pmask) HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel; geometry may differ per call)
         // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
         const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
         // persistent grid: fill the chip, but never more waves than batches

@@ -17,7 +17,7 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE = range(1, 8)
 PT_INFO_NAME, PT_INFO_BOARD, PT_INFO_VENDOR, PT_INFO_VERSION = range(4)
 (PT_OPT_BATCH_FRAMES, PT_OPT_CHUNK_FRAMES, PT_OPT_PROFILE_RETURN_TIME, PT_OPT_TRACE_VARIANT, PT_OPT_QUAD_FILTER, PT_OPT_ACCEL,
- PT_OPT_BVH_TALLY) = range(7)
+ PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS) = range(8)
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64
 PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 8

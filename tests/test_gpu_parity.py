@@ -111,6 +111,29 @@ def test_configs2_full_size_sampled_pixels(device, cornell, oracle, variant):
         assert_fb_equal(got[s:s + 64], fb[s:s + 64], "C3 pixels %d.." % s)
 
 
+@pytest.mark.parametrize("W,H,frames", [(64, 64, 8), (200, 50, 4), (33, 97, 3)])
+def test_primary_masks_on_and_off(device, cornell, oracle, W, H, frames):
+    """PT_OPT_PRIMARY_MASKS: fresh waves of primary rays take their pass-1 survivors from per-pixel candidate masks
+    (default) or run the filter like any other ray (0).  Same pixels, same ray counts, at footprints from 1/33 to
+    1/200 of the image and aspect ratios 4:1 and 1:3 (the masks' margin grows with the pixel's footprint)."""
+    from oclpathtracer_amd import shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
+    for on in (1, 0):
+        device.setOption(shim.PT_OPT_PRIMARY_MASKS, on)
+        r = Renderer(device, tris, mats, W, H, want_stats=True)
+        try:
+            r.render(frames)
+            got, gst = r.read(), r.read_stats()
+        finally:
+            r.release()
+            device.setOption(shim.PT_OPT_PRIMARY_MASKS, 1)
+        assert_fb_equal(got, want, "primary masks %d, %dx%d" % (on, W, H))
+        assert gst["rays"] == st["rays"]
+
+
 def test_resume_equals_one_shot(device, cornell):
     """Accumulation is resumable (frame is an argument, GenerateColors.cl:314-321): 3+5 frames in
     two calls == 8 frames in one, and chunked staging == unchunked."""
