@@ -195,8 +195,9 @@ def bvh_tallies(dev, lib, shim, tris, mats, W, H, depth):
     finally:
         dev.setOption(shim.PT_OPT_BVH_TALLY, 0)
     rays = max(int(st[shim.PT_STAT_RAYS]), 1)
-    return {"nodes_per_ray": int(st[shim.PT_STAT_BVH_NODES]) / rays, "tris_per_ray": int(st[shim.PT_STAT_BVH_TRIS]) / rays,
-            "wave_iterations_per_ray_wave": int(st[shim.PT_STAT_BVH_ITERS]) / max(int(st[shim.PT_STAT_BVH_WAVES]), 1)}
+    nodes, tris_, steps = int(st[shim.PT_STAT_BVH_NODES]), int(st[shim.PT_STAT_BVH_TRIS]), int(st[shim.PT_STAT_BVH_STEPS])
+    return {"nodes_per_ray": nodes / rays, "tris_per_ray": tris_ / rays,
+            "search_lane_occupancy": (nodes + tris_) / max(64 * steps, 1)}
 
 
 def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):

@@ -23,6 +23,14 @@
 #include <hipcub/hipcub.hpp>
 
 #define PT_BVH_EPS 1.2e-4f
+// BIG triangles stay out of the hierarchy.  An LBVH places a triangle by its centre: one that spans a good part of
+// the scene (the Cornell box's walls among 10^6 centimetre-sized ones) sits at a deep leaf and inflates the boxes
+// of all ~20 of its ancestors to its own size, and every ray then enters hundreds of such nodes.  Triangles whose
+// box is longer than 1/PT_BVH_BIG_DIV of the scene's longest side -- if there are at most PT_BVH_BIG_MAX of
+// them -- get an empty box in the tree and are searched by the brute-force two-pass search instead
+// (pt_trace_bvh_body), in ascending index order like the reference's loop; the closest hit is the lexicographic
+// minimum of (t, index) over both searches, so the result is unchanged.
+#define PT_BVH_BIG_DIV 16.0f
 
 namespace {
 
@@ -64,6 +72,52 @@ __global__ void pt_bvh_bounds_kernel(const PtRawTriangle* __restrict__ raw, int 
     atomicMax(&bounds[6], pt_ordered(m));
 }
 
+// bounds[8] = bit pattern of the big-triangle threshold (0x7f800000 = +Inf: no split), bounds[9] = number found
+__device__ __forceinline__ bool pt_tri_is_big(const float lo[3], const float hi[3], const unsigned* bounds)
+{
+    const float thr = __uint_as_float(bounds[8]);
+    return fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2])) > thr;
+}
+
+__global__ void pt_bvh_threshold_kernel(unsigned* __restrict__ bounds)
+{
+    float ext = 0.0f;
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, pt_unordered(bounds[3 + k]) - pt_unordered(bounds[k]));
+    bounds[8] = __float_as_uint(ext > 0.0f ? ext / PT_BVH_BIG_DIV : __builtin_inff());  // (an empty / degenerate scene: no split)
+    bounds[9] = 0u;
+}
+
+__global__ void pt_bvh_big_collect_kernel(const PtRawTriangle* __restrict__ raw, int ntri, unsigned* __restrict__ bounds,
+                                          int* __restrict__ bigidx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntri) return;
+    float lo[3], hi[3];
+    if (!pt_tri_box(raw[i], lo, hi) || !pt_tri_is_big(lo, hi, bounds)) return;
+    const unsigned k = atomicAdd(&bounds[9], 1u);
+    if (k < PT_BVH_BIG_MAX) bigidx[k] = i;
+}
+
+// one thread: too many big triangles -> no split; otherwise sort their indices ascending (ties in t go to the lowest
+// index, as in the reference's loop) and copy their prepared records
+__global__ void pt_bvh_big_finish_kernel(unsigned* __restrict__ bounds, int* __restrict__ bigidx, const PtPrepTriangle* __restrict__ prep,
+                                         PtPrepTriangle* __restrict__ bigtab, int* __restrict__ nbig_out)
+{
+    unsigned n = bounds[9];
+    if (n > PT_BVH_BIG_MAX) {
+        n = 0u;
+        bounds[8] = 0x7f800000u;  // +Inf: nothing is big
+    }
+    for (unsigned a = 1; a < n; ++a) {
+        const int v = bigidx[a];
+        unsigned b = a;
+        for (; b > 0 && bigidx[b - 1] > v; --b) bigidx[b] = bigidx[b - 1];
+        bigidx[b] = v;
+    }
+    for (unsigned a = 0; a < n; ++a) bigtab[a] = prep[bigidx[a]];
+    *nbig_out = (int)n;
+}
+
 __device__ __forceinline__ unsigned pt_expand10(unsigned v)
 {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -79,8 +133,8 @@ __global__ void pt_bvh_keys_kernel(const PtRawTriangle* __restrict__ raw, int nt
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntri) return;
     float lo[3], hi[3];
-    unsigned code = 0x3fffffffu;  // non-finite triangles sort to the end
-    if (pt_tri_box(raw[i], lo, hi)) {
+    unsigned code = 0x3fffffffu;  // non-finite and big triangles sort to the end
+    if (pt_tri_box(raw[i], lo, hi) && !pt_tri_is_big(lo, hi, bounds)) {
         unsigned q[3];
         for (int k = 0; k < 3; ++k) {
             const float smin = pt_unordered(bounds[k]), smax = pt_unordered(bounds[3 + k]);
@@ -143,7 +197,7 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     const int tri = (int)(unsigned)keys[k];
     const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
     float lo[3], hi[3];
-    if (pt_tri_box(raw[tri], lo, hi)) {
+    if (pt_tri_box(raw[tri], lo, hi) && !pt_tri_is_big(lo, hi, bounds)) {
         for (int a = 0; a < 3; ++a) { lo[a] -= eps; hi[a] += eps; }
     } else {
         for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }  // empty: never entered
@@ -180,11 +234,12 @@ size_t ptk_bvh_temp_bytes(int ntri)
     unsigned long long* nullk = nullptr;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
     const size_t n = (size_t)ntri;
-    // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[8], cub temp
+    // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], cub temp
     return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024;
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, void* temp, size_t temp_bytes, hipStream_t s)
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode* nodes, PtPrepTriangle* bigtab,
+                         int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
@@ -197,12 +252,16 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, v
     unsigned* bounds = (unsigned*)p; p += 64;
     p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     size_t cub = temp_bytes - (size_t)(p - (char*)temp);
-    const unsigned init[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0x80000000u /* ordered(0) */, 0u };
+    const unsigned init[16] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0x80000000u /* ordered(0) */, 0u,
+                                0x7f800000u /* threshold: +Inf */, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
     hipError_t e = hipMemcpyAsync(bounds, init, sizeof init, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(flags, 0, 4 * n, s)) != hipSuccess) return e;
     const dim3 blk(256), grd((ntri + 255) / 256);
     hipLaunchKernelGGL(pt_bvh_bounds_kernel, grd, blk, 0, s, raw, ntri, bounds);
+    hipLaunchKernelGGL(pt_bvh_threshold_kernel, dim3(1), dim3(1), 0, s, bounds);
+    hipLaunchKernelGGL(pt_bvh_big_collect_kernel, grd, blk, 0, s, raw, ntri, bounds, bigidx);
+    hipLaunchKernelGGL(pt_bvh_big_finish_kernel, dim3(1), dim3(1), 0, s, bounds, bigidx, prep, bigtab, nbig_dev);
     hipLaunchKernelGGL(pt_bvh_keys_kernel, grd, blk, 0, s, raw, ntri, bounds, keys);
     if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, grd, blk, 0, s, sorted, ntri, nodes, parent, right_child);

@@ -58,6 +58,9 @@ struct PtTraceParams {
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
     const PtBvhNode* bvh;         // accel = BVH: ntri-1 internal nodes, root 0
+    const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
+    const int32_t* bigidx;        //              their triangle indices, ascending
+    int32_t nbig;
     const uint2* pmask;           // quad mode 3, <= 64 triangles: per local pixel the primary rays' candidate masks of the two
                                   // 32-triangle chunks (pt_primary_mask_kernel); null = run pass 1 for primary rays too
 };
@@ -92,7 +95,11 @@ hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s);
 hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s);
 size_t ptk_bvh_node_count(int ntri);
 size_t ptk_bvh_temp_bytes(int ntri);
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, int ntri, PtBvhNode* nodes, void* temp, size_t temp_bytes, hipStream_t s);
+// prep: the prepared records of the same triangles.  bigtab[PT_BVH_BIG_MAX] / bigidx[PT_BVH_BIG_MAX] / *nbig_dev (device memory)
+// receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
+#define PT_BVH_BIG_MAX 64
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode* nodes, PtPrepTriangle* bigtab,
+                         int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);
@@ -105,3 +112,5 @@ hipError_t ptk_math(const float* in, float* out, int n, hipStream_t s);
 // per sample of every wave's current batch
 size_t ptk_trace_lds_bytes(int ntri);
 int ptk_trace_blocks_per_cu(int ntri);
+int ptk_trace_bvh_blocks_per_cu(void);
+size_t ptk_trace_bvh_lds_bytes(void);

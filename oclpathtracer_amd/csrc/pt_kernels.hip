@@ -17,7 +17,7 @@
 //                    in its strongest form one packed FMA chain deciding four triangles
 //                    (pt_quad3_pass1); pass 2 lets every lane run the exact reference test on its
 //                    own ~3 survivors, fetched per lane from an LDS copy of the records.  Scenes
-//                    of 512 triangles or more walk an LBVH instead (pt_intersect_bvh, pt_bvh.hip).
+//                    of 512 triangles or more walk an LBVH instead (pt_trace_bvh_body, pt_bvh.hip).
 //                    Path radiance goes to rad[frame][pixel].
 //   pt_fold_kernel   per pixel channel, in ascending frame order, replays the reference's
 //                    gamma -> mean -> degamma arithmetic (GenerateColors.cl:314-321) over the
@@ -776,7 +776,6 @@ PTK_DEV unsigned pt_intersect_primary(pt_const_f32p T, const PtPrepTriangle* tri
 // reference's exact test runs with pt_tri_pass2's arithmetic; because leaves are met in tree order,
 // not index order, the reference's "first triangle wins an exact tie" (:125 with ascending i)
 // becomes: accept when t < tmax, or t == tmax and the index is lower than the holder's.
-#define PT_ACCEL_BVH (-1)  // value of the trace kernel's QUADS parameter that selects this search
 
 template <bool DET_BOUNDED>
 PTK_DEV void pt_tri_exact_unordered(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
@@ -813,86 +812,6 @@ PTK_DEV bool pt_slab(const float4& bmin, const float4& bmax, const f3& o, float 
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
     // a NaN ray fails these: nothing could be accepted for it anyway (every t is NaN)
     return (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);
-}
-
-// Near-child-first traversal with a per-lane stack of far children (private memory: one entry per
-// level at most, and a radix tree over 64-bit keys has at most 64 levels).  Leaves are tested as
-// soon as their box is hit; tmax then prunes everything farther.
-#define PT_BVH_STACK 64
-// TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..5]:
-// nodes entered, triangles tested, iterations of the wave's loop, wave searches.  Never the timed kernel.
-template <bool DET_BOUNDED, bool TALLY>
-PTK_DEV void pt_intersect_bvh(const PtBvhNode* __restrict__ nodes, const PtPrepTriangle* __restrict__ tris, int ntri, const f3& o, const f3& d,
-                              bool alive, float& tmax, float& hu, float& hv, int& hidx, unsigned long long* bstat = nullptr)
-{
-    unsigned c_nodes = 0, c_leaves = 0, c_iters = 0;
-    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
-    // boxes' margin); a zero component gives +-Inf
-    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
-    unsigned stack[PT_BVH_STACK];
-    int sp = 0;
-    const unsigned n_nodes = (unsigned)ntri - 1u;
-    const unsigned DONE = 0x7fffffffu;         // (an internal-node link this large cannot exist)
-    unsigned cur = alive ? 0u : DONE;          // a link: internal node index, or 0x80000000 | triangle
-    // One 64-byte fetch per step, whatever the step is: internal nodes and prepared triangle records
-    // are both 64 bytes, so a lane at a leaf and a lane at an internal node issue the same four loads
-    // and the wave waits for memory once per step.  Leaves are not tested where their box is hit: the
-    // link goes the way of any child (next, or onto the stack behind a nearer sibling).
-    // Every link is visited at most once: the budget and the index checks make a damaged hierarchy
-    // end the search instead of hanging or faulting the GPU.
-    for (unsigned budget = 2u * (unsigned)ntri; budget != 0u && __ballot(cur != DONE) != 0ull; --budget) {
-        ++c_iters;
-        if (cur != DONE) {
-            const bool leaf = (cur & 0x80000000u) != 0u;
-            const unsigned idx = cur & 0x7fffffffu;
-            const bool in_range = leaf ? idx < (unsigned)ntri : idx < n_nodes;
-            const float4* q = leaf ? reinterpret_cast<const float4*>(tris + (in_range ? idx : 0u))
-                                   : reinterpret_cast<const float4*>(nodes + (in_range ? idx : 0u));
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            unsigned next = sp > 0 ? stack[sp - 1] : DONE;  // what a pop would give
-            bool pop = true;
-            if (!in_range) {
-                sp = 0; next = DONE;
-            } else if (leaf) {
-                ++c_leaves;
-                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z ...
-                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
-                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
-                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
-                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)idx, o, d, tmax, hu, hv, hidx);
-            } else {
-                ++c_nodes;
-                const unsigned link_l = __float_as_uint(q0.w), link_r = __float_as_uint(q1.w);
-                float tl, tr;
-                const bool hit_l = pt_slab(q0, q1, o, ix, iy, iz, tmax, tl);
-                const bool hit_r = pt_slab(q2, q3, o, ix, iy, iz, tmax, tr);
-                if (hit_l & hit_r) {
-                    const bool left_first = tl <= tr;
-                    if (sp < PT_BVH_STACK) stack[sp++] = left_first ? link_r : link_l;
-                    next = left_first ? link_l : link_r;
-                    pop = false;
-                } else if (hit_l | hit_r) {
-                    next = hit_l ? link_l : link_r;
-                    pop = false;
-                }
-            }
-            if (pop && sp > 0) --sp;
-            cur = next;
-        }
-    }
-    if (TALLY && bstat) {
-        unsigned long long n = alive ? c_nodes : 0u, l = alive ? c_leaves : 0u;
-        for (int off = 32; off > 0; off >>= 1) {
-            n += __shfl_down(n, off);
-            l += __shfl_down(l, off);
-        }
-        if (pt_lane_id() == 0) {
-            atomicAdd(&bstat[0], n);
-            atomicAdd(&bstat[1], l);
-            atomicAdd(&bstat[2], (unsigned long long)c_iters);
-            atomicAdd(&bstat[3], 1ull);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1174,7 +1093,7 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
     return count == 64u;
 }
 
-template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS, bool TALLY = false>
+template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
 PTK_DEV void pt_trace_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
@@ -1234,13 +1153,11 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
         int hidx = -1;
         unsigned p2steps = 0;
-        if (QUADS == PT_ACCEL_BVH)
-            pt_intersect_bvh<DET_BOUNDED, TALLY>(P.bvh, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.stats ? P.stats + 2 : nullptr);
-        else if (QUADS == 3 && DET_BOUNDED && primary && P.pmask != nullptr)
+        if (QUADS == 3 && DET_BOUNDED && primary && P.pmask != nullptr)
             p2steps = pt_intersect_primary<DET_BOUNDED, LDS_TABLE>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx, P.pmask[s.lp], tl, lane,
                                                                    PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr);
         else
-            p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, (QUADS < 0 ? 0 : QUADS)>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
+            p2steps = pt_intersect_two_pass<DET_BOUNDED, LDS_TABLE, QUADS>(T, P.tris, ntri, s.o, s.d, alive, tmax, hu, hv, hidx,
                                                                                           P.quad_delta1, P.ray_radius,
                                                                                           (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi, tl, lane,
                                                                                           PT_VALIDATE_FILTER && P.stats ? P.stats + 2 : nullptr,
@@ -1301,13 +1218,196 @@ void pt_trace_kernel(const PtTraceParams P)
     pt_trace_body<DET_BOUNDED, LDS_TABLE, QUADS>(P);
 }
 
-// the LBVH search keeps a traversal stack and two boxes live: it gets the registers it asks for
-// (5 waves per SIMD) instead of the brute-force kernel's 7-wave diet
+// ---- the LBVH trace kernel -------------------------------------------------------------------------
+// Lane = path, and every lane walks its own ray through the hierarchy (near child first, far child on a per-lane
+// stack) -- but rays differ wildly in how many nodes they enter, so a wave that waits for its slowest lane before
+// shading runs the search at a third of its lanes (round 1: 34 %).  Here the search is a per-lane STATE that
+// survives the shading phase: the wave steps all traversing lanes together, and as soon as no more than
+// PT_BVH_REFILL of them are still traversing, the finished lanes are shaded, dead ones take new samples, and all of
+// them start their next search while the stragglers simply keep theirs.  Lane occupancy of the search stays
+// between PT_BVH_REFILL/64 and 1.
+//   * per-lane stack: PT_BVH_LDS_STACK entries in LDS (entry-major: conflict-free), deeper ones in a private array;
+//   * the triangles the builder kept out of the hierarchy (pt_bvh.hip: the few that span the scene) are searched
+//     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
+//   * one 64-byte fetch per step whatever the step is: internal nodes and prepared triangle records are both
+//     64 bytes, so a lane at a leaf and a lane at an internal node issue the same four loads;
+//   * every link is visited at most once; a step budget and index checks make a damaged hierarchy end the
+//     search instead of hanging or faulting the GPU.
+// TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
+// triangles tested (both per lane), traversal steps of the waves.  Never the timed kernel.
+#define PT_BVH_STACK 64        // a radix tree over 64-bit keys has at most 64 levels
+#define PT_BVH_LDS_STACK 24
+#ifndef PT_BVH_REFILL
+#define PT_BVH_REFILL 40
+#endif
+
+// dead lanes take the next samples of the wave's range, one by one (no coherence to keep here: the search dominates)
+PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
+{
+    unsigned long long need = __ballot(!alive);
+    while (need != 0ull && pt_queue_refill(P, lane, q)) {
+        const unsigned n_need = (unsigned)__popcll(need);
+        const unsigned avail = q.end - q.pix;
+        const unsigned take = n_need < avail ? n_need : avail;
+        const unsigned rank = pt_mbcnt(need);
+        if (!alive && rank < take) {
+            const unsigned lp = q.pix + rank;
+            const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+            unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
+            if (P.n_ranks > 1) {
+                const unsigned sl = lr / (unsigned)P.stripe_rows;
+                const unsigned within = lr - sl * (unsigned)P.stripe_rows;
+                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+            }
+            const unsigned gid = grow * (unsigned)P.width + x;
+            const int frame = P.frame_begin + (int)q.frame;
+            s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
+            pt_generate_ray((int)x, (int)grow, P.width, P.height, s.seed, s.o, s.d);      // :310
+            s.mask = mk3(1.0f, 1.0f, 1.0f);
+            s.L = mk3(0.0f, 0.0f, 0.0f);
+            s.bounce = 0;
+            s.lp = lp;
+            s.fl = q.frame;
+            alive = true;
+        }
+        q.pix += take;
+        need = __ballot(!alive);
+    }
+}
+
+template <bool DET_BOUNDED, bool TALLY>
+PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
+{
+    const unsigned lane = pt_lane_id();
+    const int ntri = P.ntri;
+    const unsigned n_nodes = (unsigned)ntri - 1u;
+    const unsigned DONE = 0x7fffffffu;  // (an internal-node link this large cannot exist)
+    // LDS: the stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
+    pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + threadIdx.x;  // entry e of this lane: stk[e * PT_TRACE_THREADS]
+    unsigned ovf[PT_BVH_STACK - PT_BVH_LDS_STACK];
+    PtTail tl;
+    {
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + PT_BVH_LDS_STACK * PT_TRACE_THREADS + (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
+        tl.keys = (pt_lds_u64*)w;
+        tl.list = w + 128;
+        tl.wr = tl.rd = 0u;
+        tl.keys[lane] = ~0ull;
+    }
+    pt_const_f32p bigT = (pt_const_f32p)(const float*)P.bigtab;
+
+    PtWaveQueue q = { 0u, 0u, 0u, false };
+    bool alive = false;  // the lane holds a path
+    bool trav = false;   // ... whose closest-hit search is in progress
+    PtPath s;
+    s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
+    s.mask = mk3(1.0f, 1.0f, 1.0f); s.L = mk3(0.0f, 0.0f, 0.0f);
+    s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
+    unsigned n_rays = 0, n_samples = 0;
+    // the search's state
+    float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
+    int hidx = -1;
+    unsigned cur = DONE;   // a link: internal node index, or 0x80000000 | triangle
+    int sp = 0;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+    unsigned budget = 0u;
+    unsigned c_nodes = 0, c_leaves = 0;
+    unsigned long long c_steps = 0;
+
+    for (;;) {
+        if ((unsigned)__popcll(__ballot(trav)) <= (unsigned)PT_BVH_REFILL) {
+            if (alive && !trav) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+            pt_regenerate_lanes(P, lane, q, s, alive);
+            const bool start = alive && !trav;
+            if (__ballot(start) != 0ull) {
+                if (start) { tmax = 1e20f; hu = 0.0f; hv = 0.0f; hidx = -1; }
+                if (P.nbig > 0) {
+                    // the triangles outside the hierarchy, in ascending index order; hp = position in their table
+                    int hp = -1;
+                    pt_intersect_two_pass<DET_BOUNDED, false, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
+                                                                 nullptr, 0.0f, 0.0f, tl, lane);
+                    if (start && hp >= 0) hidx = P.bigidx[hp];
+                }
+                if (start) {
+                    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
+                    // boxes' margin); a zero component gives +-Inf
+                    ix = __builtin_amdgcn_rcpf(s.d.x); iy = __builtin_amdgcn_rcpf(s.d.y); iz = __builtin_amdgcn_rcpf(s.d.z);
+                    cur = 0u;
+                    sp = 0;
+                    budget = 2u * (unsigned)ntri;
+                    trav = true;
+                }
+            }
+            if (__ballot(alive) == 0ull) break;
+        }
+        // ---- one step of every traversing lane ---------------------------------------------------
+        if (TALLY) ++c_steps;
+        if (trav) {
+            const bool leaf = (cur & 0x80000000u) != 0u;
+            const unsigned idx = cur & 0x7fffffffu;
+            const bool in_range = leaf ? idx < (unsigned)ntri : idx < n_nodes;
+            const float4* qp = leaf ? reinterpret_cast<const float4*>(P.tris + (in_range ? idx : 0u))
+                                    : reinterpret_cast<const float4*>(P.bvh + (in_range ? idx : 0u));
+            const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+            unsigned next = DONE;
+            bool pop = true;
+            if (!in_range) {
+                sp = 0;
+            } else if (leaf) {
+                if (TALLY) ++c_leaves;
+                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z ...
+                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
+                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)idx, s.o, s.d, tmax, hu, hv, hidx);
+            } else {
+                if (TALLY) ++c_nodes;
+                const unsigned link_l = __float_as_uint(q0.w), link_r = __float_as_uint(q1.w);
+                float tl_, tr_;
+                const bool hit_l = pt_slab(q0, q1, s.o, ix, iy, iz, tmax, tl_);
+                const bool hit_r = pt_slab(q2, q3, s.o, ix, iy, iz, tmax, tr_);
+                if (hit_l & hit_r) {
+                    const bool left_first = tl_ <= tr_;
+                    const unsigned far = left_first ? link_r : link_l;
+                    if (sp < PT_BVH_LDS_STACK) stk[sp * PT_TRACE_THREADS] = far;
+                    else if (sp < PT_BVH_STACK) ovf[sp - PT_BVH_LDS_STACK] = far;
+                    sp = sp < PT_BVH_STACK ? sp + 1 : sp;
+                    next = left_first ? link_l : link_r;
+                    pop = false;
+                } else if (hit_l | hit_r) {
+                    next = hit_l ? link_l : link_r;
+                    pop = false;
+                }
+            }
+            if (pop && sp > 0) {
+                --sp;
+                next = sp < PT_BVH_LDS_STACK ? stk[sp * PT_TRACE_THREADS] : ovf[sp - PT_BVH_LDS_STACK];
+            }
+            cur = next;
+            --budget;
+            if (next == DONE || budget == 0u) trav = false;
+        }
+    }
+
+    if (TALLY && P.stats) {
+        unsigned long long n = c_nodes, l = c_leaves;
+        for (int off = 32; off > 0; off >>= 1) {
+            n += __shfl_down(n, off);
+            l += __shfl_down(l, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&P.stats[2], n);
+            atomicAdd(&P.stats[3], l);
+            atomicAdd(&P.stats[4], c_steps);
+        }
+    }
+    pt_flush_counters(P, lane, n_rays, n_samples);
+}
+
 template <bool DET_BOUNDED, bool TALLY>
 __global__ __launch_bounds__(PT_TRACE_THREADS)
 void pt_trace_bvh_kernel(const PtTraceParams P)
 {
-    pt_trace_body<DET_BOUNDED, false, PT_ACCEL_BVH, TALLY>(P);
+    pt_trace_bvh_body<DET_BOUNDED, TALLY>(P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1455,7 +1555,7 @@ hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s)
 hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s)
 {
     if (bvh) {
-        const size_t lds = ptk_trace_lds_bytes(PT_LDS_TRI_MAX + 1);  // camera slots only
+        const size_t lds = ptk_trace_bvh_lds_bytes();
         if (tally) {
             if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
             else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
@@ -1524,6 +1624,20 @@ size_t ptk_trace_lds_bytes(int ntri)
     const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
     // per wave: the pool of parked paths (PT_POOL x 64 B) + the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
     return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL * 4 * sizeof(float4) + 64 * 8 + PT_TAIL_LIST * 4);
+}
+
+size_t ptk_trace_bvh_lds_bytes(void)
+{
+    // the 256 lanes' stacks + per wave the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
+    return (size_t)PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
+}
+
+int ptk_trace_bvh_blocks_per_cu(void)
+{
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_bvh_kernel<true, false>, PT_TRACE_THREADS, ptk_trace_bvh_lds_bytes());
+    if (e != hipSuccess || nb < 1) nb = 2;
+    return nb;
 }
 
 int ptk_trace_blocks_per_cu(int ntri)

@@ -99,6 +99,10 @@ struct pt_device_s {
                                 // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
     PtBvhNode* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
+    PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
+    int* bigidx;
+    int nbig;
+    int bvh_blocks_per_cu;
     bool bvh_valid;
     float* p1tab;               // quad mode 3: packed pass-1 table (pt_quad3_pass1), sized with prep
     float prep_p1_lo, prep_p1_hi;
@@ -216,13 +220,16 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
-    if (hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
+    if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
+        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
         return fail(PT_ERR_OOM, "workspace allocation failed");
     }
     d->blocks_per_cu = ptk_trace_blocks_per_cu(36);
+    d->bvh_blocks_per_cu = ptk_trace_bvh_blocks_per_cu();
     d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
     *out = d;
     return PT_OK;
@@ -244,6 +251,8 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->rad) hipFree(d->rad);
     if (d->pmask) hipFree(d->pmask);
     if (d->counters) hipFree(d->counters);
+    if (d->bigtab) hipFree(d->bigtab);
+    if (d->bigidx) hipFree(d->bigidx);
     if (d->det_bound_dev) hipFree(d->det_bound_dev);
     for (int k = 0; k < PT_PROF_KINDS; ++k)
         for (auto& pr : d->prof_pairs[k]) {
@@ -744,10 +753,14 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     void* temp = nullptr;
     hipError_t e = hipMalloc(&temp, temp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH build workspace allocation failed: %s", hipGetErrorString(e)); }
-    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, ntri, d->bvh, temp, temp_bytes, d->stream);
+    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, temp, temp_bytes,
+                      d->stream);
+    int nbig = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&nbig, d->bigidx + PT_BVH_BIG_MAX, sizeof nbig, hipMemcpyDeviceToHost, d->stream);
     hipError_t e2 = hipStreamSynchronize(d->stream);  // once per scene upload; the workspace is freed right after
     hipFree(temp);
     if (e != hipSuccess || e2 != hipSuccess) return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    d->nbig = nbig < 0 ? 0 : (nbig > PT_BVH_BIG_MAX ? PT_BVH_BIG_MAX : nbig);
     d->bvh_valid = true;
     return PT_OK;
 }
@@ -839,7 +852,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     // Samples per work-queue grab.  A wave that finds the queue empty idles until the last wave is
     // done, on average for half a batch: large batches (fewer atomics) when every wave gets many of
     // them, smaller ones when the launch is short (a rank's share of a multi-GPU render, small images).
-    const uint64_t resident_waves = (uint64_t)d->prop.multiProcessorCount * (uint64_t)d->blocks_per_cu * (PT_TRACE_THREADS / 64);
+    const uint64_t resident_waves = (uint64_t)d->prop.multiProcessorCount * (uint64_t)(use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu) * (PT_TRACE_THREADS / 64);
     const uint64_t chunk_samples = (uint64_t)npix * (uint64_t)std::min(chunk, rp.frame_count);
     // (not below 128: at 64 the ONE queue counter takes 4 M atomics per launch of configs[2] and the
     // L2 atomic unit saturates -- measured +30 % launch time)
@@ -878,6 +891,9 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
+        tp.bigtab = d->bigtab;
+        tp.bigidx = d->bigidx;
+        tp.nbig = use_bvh ? d->nbig : 0;
         tp.pmask = use_pmask ? d->pmask : nullptr;
         if (c == 0 && use_pmask) HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel; geometry may differ per call)
         // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
@@ -885,7 +901,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         // persistent grid: fill the chip, but never more waves than batches
         const int wg_waves = PT_TRACE_THREADS / 64;
         uint64_t waves_needed = total_batches;
-        int blocks = d->prop.multiProcessorCount * d->blocks_per_cu;
+        int blocks = d->prop.multiProcessorCount * (use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu);
         uint64_t blocks_needed = (waves_needed + wg_waves - 1) / wg_waves;
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
         hipEvent_t pstop;
