@@ -179,9 +179,9 @@ __global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ k
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     const int left = lo == gamma ? n - 1 + gamma : gamma;
     const int right = hi == gamma + 1 ? n - 1 + gamma + 1 : gamma + 1;
-    // links: internal child = its index; leaf child = 0x80000000 | triangle (keys carry the index)
-    nodes[i].link_l = left >= n - 1 ? 0x80000000u | (unsigned)keys[left - (n - 1)] : (unsigned)left;
-    nodes[i].link_r = right >= n - 1 ? 0x80000000u | (unsigned)keys[right - (n - 1)] : (unsigned)right;
+    // links: internal child = its index; leaf child = 0x80000000 | position in the sorted order
+    nodes[i].link_l = left >= n - 1 ? 0x80000000u | (unsigned)(left - (n - 1)) : (unsigned)left;
+    nodes[i].link_r = right >= n - 1 ? 0x80000000u | (unsigned)(right - (n - 1)) : (unsigned)right;
     right_child[i] = right;
     parent[left] = i;
     parent[right] = i;
@@ -224,6 +224,77 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     }
 }
 
+// the prepared records in leaf order, each carrying its triangle index (pad0[0]): a leaf is one contiguous fetch
+__global__ void pt_bvh_sorted_tris_kernel(const unsigned long long* __restrict__ keys, int n, const PtPrepTriangle* __restrict__ prep,
+                                          PtPrepTriangle* __restrict__ stris)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned tri = (unsigned)keys[k];
+    PtPrepTriangle t = prep[tri];
+    t.pad0[0] = __uint_as_float(tri);
+    stris[k] = t;
+}
+
+__device__ __forceinline__ float pt_bvh_decode(unsigned q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
+
+// fp32 node -> the 32-byte node the traversal reads (PtBvhNode32): conservative 8-bit boxes, verified by decoding
+__global__ void pt_bvh_compress_kernel(const PtBvhNode* __restrict__ wide, int n, PtBvhNode32* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const PtBvhNode w = wide[i];
+    const float* lo[2] = { w.lmin, w.rmin };
+    const float* hi[2] = { w.lmax, w.rmax };
+    bool absent[2];
+    for (int c = 0; c < 2; ++c) {
+        absent[c] = false;
+        for (int a = 0; a < 3; ++a) absent[c] = absent[c] || !(lo[c][a] <= hi[c][a]);  // empty (3e38, -3e38) or NaN
+    }
+    PtBvhNode32 o;
+    unsigned flags = ((w.link_l & 0x80000000u) ? PT_BVH_LEFT_LEAF : 0u) | ((w.link_r & 0x80000000u) ? PT_BVH_RIGHT_LEAF : 0u) |
+                     (absent[0] ? PT_BVH_LEFT_ABSENT : 0u) | (absent[1] ? PT_BVH_RIGHT_ABSENT : 0u);
+    o.gamma = w.link_l & 0x7fffffffu;  // (the right child is gamma + 1: pt_bvh_hierarchy_kernel)
+    unsigned ex[3] = { 1u, 1u, 1u };
+    for (int a = 0; a < 3; ++a) {
+        float org = 3.0e38f, top = -3.0e38f;
+        for (int c = 0; c < 2; ++c)
+            if (!absent[c]) { org = fminf(org, lo[c][a]); top = fmaxf(top, hi[c][a]); }
+        if (absent[0] && absent[1]) { org = 0.0f; top = 0.0f; }
+        o.origin[a] = org;
+        // smallest power of two `step` with decode(255) >= top; then every bound rounded outward and CHECKED with the
+        // traversal's own decode expression
+        int e2 = 0;
+        const float ext = top - org;
+        if (ext > 0.0f) { (void)frexpf(ext / 255.0f, &e2); } else { e2 = -126; }
+        int be = e2 + 127;  // biased exponent of 2^e2
+        be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        for (;;) {
+            const float step = __uint_as_float((unsigned)be << 23);
+            bool ok = true;
+            for (int c = 0; c < 2 && ok; ++c) {
+                unsigned ql = 255u, qh = 0u;  // an absent child: inverted, and flagged
+                if (!absent[c]) {
+                    float fl = floorf((lo[c][a] - org) / step), fh = ceilf((hi[c][a] - org) / step);
+                    fl = fminf(fmaxf(fl, 0.0f), 255.0f);
+                    fh = fminf(fmaxf(fh, 0.0f), 255.0f);
+                    ql = (unsigned)fl; qh = (unsigned)fh;
+                    while (ql > 0u && pt_bvh_decode(ql, step, org) > lo[c][a]) --ql;
+                    while (qh < 255u && pt_bvh_decode(qh, step, org) < hi[c][a]) ++qh;
+                    if (pt_bvh_decode(ql, step, org) > lo[c][a] || pt_bvh_decode(qh, step, org) < hi[c][a]) ok = false;
+                }
+                o.q[6 * c + a] = (uint8_t)ql;
+                o.q[6 * c + 3 + a] = (uint8_t)qh;
+            }
+            if (ok || be >= 254) break;  // (be = 254 always suffices for finite boxes: 255 x 2^127 spans binary32)
+            ++be;
+        }
+        ex[a] = (unsigned)be;
+    }
+    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (flags << 24);
+    out[i] = o;
+}
+
 }  // namespace
 
 size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ntri - 1 : 0; }
@@ -235,11 +306,11 @@ size_t ptk_bvh_temp_bytes(int ntri)
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
     const size_t n = (size_t)ntri;
     // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], cub temp
-    return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024;
+    return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024 + sizeof(PtBvhNode) * n + 256;  // + the fp32 nodes
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode* nodes, PtPrepTriangle* bigtab,
-                         int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode32* nodes32, PtPrepTriangle* stris,
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
@@ -250,6 +321,8 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     int* right_child = (int*)p; p += 4 * n;
     int* flags = (int*)p; p += 4 * n;
     unsigned* bounds = (unsigned*)p; p += 64;
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    PtBvhNode* nodes = (PtBvhNode*)p; p += sizeof(PtBvhNode) * n;  // fp32 nodes: refit works on these, then compressed
     p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     size_t cub = temp_bytes - (size_t)(p - (char*)temp);
     const unsigned init[16] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0x80000000u /* ordered(0) */, 0u,
@@ -266,5 +339,7 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, grd, blk, 0, s, sorted, ntri, nodes, parent, right_child);
     hipLaunchKernelGGL(pt_bvh_refit_kernel, grd, blk, 0, s, raw, sorted, ntri, bounds, nodes, parent, right_child, flags);
+    hipLaunchKernelGGL(pt_bvh_compress_kernel, grd, blk, 0, s, nodes, ntri, nodes32);
+    hipLaunchKernelGGL(pt_bvh_sorted_tris_kernel, grd, blk, 0, s, sorted, ntri, prep, stris);
     return hipGetLastError();
 }

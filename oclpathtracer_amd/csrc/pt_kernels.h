@@ -34,6 +34,25 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
+// The node the trace kernel walks: 32 bytes = two 16-byte loads.  The search is bound by the CU's vector-memory
+// address path (every lane fetches its own node: 64 cache lines per load instruction), so bytes per node are what
+// count.  Both children's boxes are quantised to 8 bits per coordinate inside the node's own frame (origin =
+// lower corner of the children's union, one power-of-two step per axis), rounded OUTWARD and verified at build
+// time with the very expression the traversal decodes them with (fma(q, step, origin)): the decoded box contains
+// the fp32 box.  In Karras' numbering the two children of a node are always (gamma, gamma + 1) -- internal node
+// indices, or positions in the Morton-sorted triangle order for leaves -- so one index serves both.
+struct PtBvhNode32 {
+    float origin[3];
+    uint32_t meta;    // step exponents (biased as in binary32) x | y << 8 | z << 16, flags << 24
+    uint32_t gamma;   // left child = gamma, right child = gamma + 1
+    uint8_t q[12];    // left min xyz, left max xyz, right min xyz, right max xyz
+};
+static_assert(sizeof(PtBvhNode32) == 32, "compressed bvh node layout");
+#define PT_BVH_LEFT_LEAF 1u     // flags: the child is a triangle (position in the sorted order), not a node
+#define PT_BVH_RIGHT_LEAF 2u
+#define PT_BVH_LEFT_ABSENT 4u   // flags: nothing below this child can be hit (non-finite triangles, triangles kept
+#define PT_BVH_RIGHT_ABSENT 8u  //        out of the hierarchy)
+
 #define PT_TRACE_BATCH 256u    // largest number of samples per work-queue grab of a wave (PtTraceParams::batch)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
 #define PT_LDS_TRI_STRIDE 12    // dwords per triangle record in the LDS copy (p1, e1, e2, 3 pad)
@@ -57,7 +76,8 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvhNode* bvh;         // accel = BVH: ntri-1 internal nodes, root 0
+    const PtBvhNode32* bvh;       // accel = BVH: ntri-1 internal nodes, root 0
+    const PtPrepTriangle* stris;  // accel = BVH: the prepared records in Morton-sorted (leaf) order, pad0[0] = triangle index
     const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
     const int32_t* bigidx;        //              their triangle indices, ascending
     int32_t nbig;
@@ -98,8 +118,9 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // prep: the prepared records of the same triangles.  bigtab[PT_BVH_BIG_MAX] / bigidx[PT_BVH_BIG_MAX] / *nbig_dev (device memory)
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode* nodes, PtPrepTriangle* bigtab,
-                         int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
+// nodes[ntri-1] and stris[ntri] (device memory) receive the hierarchy the trace kernel walks
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode32* nodes, PtPrepTriangle* stris,
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);

@@ -1229,8 +1229,9 @@ void pt_trace_kernel(const PtTraceParams P)
 //   * per-lane stack: PT_BVH_LDS_STACK entries in LDS (entry-major: conflict-free), deeper ones in a private array;
 //   * the triangles the builder kept out of the hierarchy (pt_bvh.hip: the few that span the scene) are searched
 //     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
-//   * one 64-byte fetch per step whatever the step is: internal nodes and prepared triangle records are both
-//     64 bytes, so a lane at a leaf and a lane at an internal node issue the same four loads;
+//   * the search is bound by the CU's vector-memory address path (every lane fetches its own record: 64 cache
+//     lines per load instruction), so a node is 32 bytes = two loads (PtBvhNode32: 8-bit boxes in the node's own
+//     frame, conservative by construction), and a leaf reads 48 bytes of the Morton-sorted copy of the records;
 //   * every link is visited at most once; a step budget and index checks make a damaged hierarchy end the
 //     search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
@@ -1282,12 +1283,22 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     const int ntri = P.ntri;
     const unsigned n_nodes = (unsigned)ntri - 1u;
     const unsigned DONE = 0x7fffffffu;  // (an internal-node link this large cannot exist)
-    // LDS: the stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
-    pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + threadIdx.x;  // entry e of this lane: stk[e * PT_TRACE_THREADS]
+    // LDS: the table of the triangles outside the hierarchy (pass 2 fetches its records per lane: pt_fetch_rec), the
+    // stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
+    {
+        const float* g = reinterpret_cast<const float*>(P.bigtab);
+        for (int k = (int)threadIdx.x; k < P.nbig * PT_LDS_TRI_STRIDE; k += PT_TRACE_THREADS) {
+            const int tri = k / PT_LDS_TRI_STRIDE, w = k - tri * PT_LDS_TRI_STRIDE;
+            pt_lds_tab[k] = g[tri * 16 + w];
+        }
+        __syncthreads();
+    }
+    pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + threadIdx.x;  // entry e of this lane: stk[e * PT_TRACE_THREADS]
     unsigned ovf[PT_BVH_STACK - PT_BVH_LDS_STACK];
     PtTail tl;
     {
-        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + PT_BVH_LDS_STACK * PT_TRACE_THREADS + (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + PT_BVH_LDS_STACK * PT_TRACE_THREADS +
+                        (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
@@ -1323,7 +1334,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (P.nbig > 0) {
                     // the triangles outside the hierarchy, in ascending index order; hp = position in their table
                     int hp = -1;
-                    pt_intersect_two_pass<DET_BOUNDED, false, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
+                    pt_intersect_two_pass<DET_BOUNDED, true, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
                                                                  nullptr, 0.0f, 0.0f, tl, lane);
                     if (start && hp >= 0) hidx = P.bigidx[hp];
                 }
@@ -1345,26 +1356,40 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             const bool leaf = (cur & 0x80000000u) != 0u;
             const unsigned idx = cur & 0x7fffffffu;
             const bool in_range = leaf ? idx < (unsigned)ntri : idx < n_nodes;
-            const float4* qp = leaf ? reinterpret_cast<const float4*>(P.tris + (in_range ? idx : 0u))
-                                    : reinterpret_cast<const float4*>(P.bvh + (in_range ? idx : 0u));
-            const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
             unsigned next = DONE;
             bool pop = true;
             if (!in_range) {
                 sp = 0;
             } else if (leaf) {
                 if (TALLY) ++c_leaves;
-                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z ...
+                const float4* qp = reinterpret_cast<const float4*>(P.stris + idx);
+                const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
                 r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
                 r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
                 r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
-                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)idx, s.o, s.d, tmax, hu, hv, hidx);
+                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), s.o, s.d, tmax, hu, hv, hidx);
             } else {
                 if (TALLY) ++c_nodes;
-                const unsigned link_l = __float_as_uint(q0.w), link_r = __float_as_uint(q1.w);
+                const uint4* np = reinterpret_cast<const uint4*>(P.bvh + idx);
+                const uint4 w0 = np[0], w1 = np[1];
+                const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+                const unsigned meta = w0.w, flags = meta >> 24;
+                const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
+                            sz = __uint_as_float(((meta >> 16) & 255u) << 23);
+                // decode exactly as pt_bvh_compress_kernel verified: fma(q, step, origin)
+                float4 lmin, lmax, rmin, rmax;
+                lmin.x = pt_fma((float)(w1.y & 255u), sx, ox);         lmin.y = pt_fma((float)((w1.y >> 8) & 255u), sy, oy);
+                lmin.z = pt_fma((float)((w1.y >> 16) & 255u), sz, oz); lmax.x = pt_fma((float)(w1.y >> 24), sx, ox);
+                lmax.y = pt_fma((float)(w1.z & 255u), sy, oy);         lmax.z = pt_fma((float)((w1.z >> 8) & 255u), sz, oz);
+                rmin.x = pt_fma((float)((w1.z >> 16) & 255u), sx, ox); rmin.y = pt_fma((float)(w1.z >> 24), sy, oy);
+                rmin.z = pt_fma((float)(w1.w & 255u), sz, oz);         rmax.x = pt_fma((float)((w1.w >> 8) & 255u), sx, ox);
+                rmax.y = pt_fma((float)((w1.w >> 16) & 255u), sy, oy); rmax.z = pt_fma((float)(w1.w >> 24), sz, oz);
+                const unsigned link_l = w1.x | ((flags & PT_BVH_LEFT_LEAF) ? 0x80000000u : 0u);
+                const unsigned link_r = (w1.x + 1u) | ((flags & PT_BVH_RIGHT_LEAF) ? 0x80000000u : 0u);
                 float tl_, tr_;
-                const bool hit_l = pt_slab(q0, q1, s.o, ix, iy, iz, tmax, tl_);
-                const bool hit_r = pt_slab(q2, q3, s.o, ix, iy, iz, tmax, tr_);
+                const bool hit_l = pt_slab(lmin, lmax, s.o, ix, iy, iz, tmax, tl_) & !(flags & PT_BVH_LEFT_ABSENT);
+                const bool hit_r = pt_slab(rmin, rmax, s.o, ix, iy, iz, tmax, tr_) & !(flags & PT_BVH_RIGHT_ABSENT);
                 if (hit_l & hit_r) {
                     const bool left_first = tl_ <= tr_;
                     const unsigned far = left_first ? link_r : link_l;
@@ -1628,8 +1653,8 @@ size_t ptk_trace_lds_bytes(int ntri)
 
 size_t ptk_trace_bvh_lds_bytes(void)
 {
-    // the 256 lanes' stacks + per wave the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
-    return (size_t)PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
+    // the big-triangle table + the 256 lanes' stacks + per wave the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
+    return (size_t)PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE * 4 + (size_t)PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
 }
 
 int ptk_trace_bvh_blocks_per_cu(void)
