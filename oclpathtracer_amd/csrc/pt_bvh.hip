@@ -188,19 +188,27 @@ __global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ k
     if (i == 0) parent[0] = -1;
 }
 
-__global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ keys, int n,
+// leaf c of the hierarchy = the sorted triangles [c << shift, (c + 1) << shift): its key is its first triangle's
+__global__ void pt_bvh_leaf_keys_kernel(const unsigned long long* __restrict__ keys, int nleaves, int shift, unsigned long long* __restrict__ lkeys)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nleaves) lkeys[c] = keys[(size_t)c << shift];
+}
+
+// n = number of leaves; tkeys = the sorted triangle keys (ntri of them)
+__global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ tkeys, int ntri, int shift, int n,
                                     const unsigned* __restrict__ bounds, PtBvhNode* nodes,
                                     const int* __restrict__ parent, const int* __restrict__ right_child, int* __restrict__ flags)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const int tri = (int)(unsigned)keys[k];
     const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
-    float lo[3], hi[3];
-    if (pt_tri_box(raw[tri], lo, hi) && !pt_tri_is_big(lo, hi, bounds)) {
-        for (int a = 0; a < 3; ++a) { lo[a] -= eps; hi[a] += eps; }
-    } else {
-        for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }  // empty: never entered
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };  // empty: never entered
+    for (int t = k << shift; t < ((k + 1) << shift) && t < ntri; ++t) {
+        const int tri = (int)(unsigned)tkeys[t];
+        float tlo[3], thi[3];
+        if (pt_tri_box(raw[tri], tlo, thi) && !pt_tri_is_big(tlo, thi, bounds))
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tlo[a] - eps); hi[a] = fmaxf(hi[a], thi[a] + eps); }
     }
     // climb: a child stores its box in its parent's record; the second child to arrive unions the two
     // and carries the result one level up.  (A radix tree over 64-bit keys is at most 64 levels deep:
@@ -224,80 +232,108 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     }
 }
 
-// the prepared records in leaf order, each carrying its triangle index (pad0[0]): a leaf is one contiguous fetch
-__global__ void pt_bvh_sorted_tris_kernel(const unsigned long long* __restrict__ keys, int n, const PtPrepTriangle* __restrict__ prep,
-                                          PtPrepTriangle* __restrict__ stris)
+// the triangles in leaf order, 48 bytes each, carrying their index: a leaf is one contiguous run of records
+__global__ void pt_bvh_leaf_tris_kernel(const unsigned long long* __restrict__ keys, int n, const PtPrepTriangle* __restrict__ prep,
+                                        PtLeafTri* __restrict__ ltris)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const unsigned tri = (unsigned)keys[k];
-    PtPrepTriangle t = prep[tri];
-    t.pad0[0] = __uint_as_float(tri);
-    stris[k] = t;
+    const PtPrepTriangle t = prep[tri];
+    PtLeafTri r;
+    for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
+    r.index = tri;
+    r.pad[0] = r.pad[1] = 0.0f;
+    ltris[k] = r;
 }
 
 __device__ __forceinline__ float pt_bvh_decode(unsigned q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
 
-// fp32 node -> the 32-byte node the traversal reads (PtBvhNode32): conservative 8-bit boxes, verified by decoding
-__global__ void pt_bvh_compress_kernel(const PtBvhNode* __restrict__ wide, int n, PtBvhNode32* __restrict__ out)
+// binary fp32 nodes -> the 64-byte four-child nodes the traversal reads (PtBvhNode4).  One thread per binary node;
+// nodes at odd depth are absorbed into their parents and write nothing.
+__global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n, PtBvhNode4* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    int depth = 0;
+    for (int p = parent[i]; p >= 0 && depth < 256; p = parent[p]) ++depth;
+    if (depth & 1) return;
+    // the (up to four) children: a child of the binary node that is a leaf stays; an internal child is replaced by its two
+    unsigned link[4] = { PT_BVH_ABSENT, PT_BVH_ABSENT, PT_BVH_ABSENT, PT_BVH_ABSENT };
+    float lo[4][3], hi[4][3];
+    int m = 0;
     const PtBvhNode w = wide[i];
-    const float* lo[2] = { w.lmin, w.rmin };
-    const float* hi[2] = { w.lmax, w.rmax };
-    bool absent[2];
     for (int c = 0; c < 2; ++c) {
-        absent[c] = false;
-        for (int a = 0; a < 3; ++a) absent[c] = absent[c] || !(lo[c][a] <= hi[c][a]);  // empty (3e38, -3e38) or NaN
+        const unsigned l = c ? w.link_r : w.link_l;
+        const float* blo = c ? w.rmin : w.lmin;
+        const float* bhi = c ? w.rmax : w.lmax;
+        if (l & 0x80000000u) {
+            link[m] = l;
+            for (int a = 0; a < 3; ++a) { lo[m][a] = blo[a]; hi[m][a] = bhi[a]; }
+            ++m;
+        } else {
+            const PtBvhNode g = wide[l];
+            link[m] = g.link_l;
+            for (int a = 0; a < 3; ++a) { lo[m][a] = g.lmin[a]; hi[m][a] = g.lmax[a]; }
+            ++m;
+            link[m] = g.link_r;
+            for (int a = 0; a < 3; ++a) { lo[m][a] = g.rmin[a]; hi[m][a] = g.rmax[a]; }
+            ++m;
+        }
     }
-    PtBvhNode32 o;
-    unsigned flags = ((w.link_l & 0x80000000u) ? PT_BVH_LEFT_LEAF : 0u) | ((w.link_r & 0x80000000u) ? PT_BVH_RIGHT_LEAF : 0u) |
-                     (absent[0] ? PT_BVH_LEFT_ABSENT : 0u) | (absent[1] ? PT_BVH_RIGHT_ABSENT : 0u);
-    o.gamma = w.link_l & 0x7fffffffu;  // (the right child is gamma + 1: pt_bvh_hierarchy_kernel)
+    bool present[4] = { false, false, false, false };
+    for (int k = 0; k < m; ++k) {
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) ok = ok && (lo[k][a] <= hi[k][a]);  // empty (3e38, -3e38) or NaN boxes are absent
+        present[k] = ok;
+        if (!ok) link[k] = PT_BVH_ABSENT;
+    }
+    PtBvhNode4 o;
     unsigned ex[3] = { 1u, 1u, 1u };
     for (int a = 0; a < 3; ++a) {
         float org = 3.0e38f, top = -3.0e38f;
-        for (int c = 0; c < 2; ++c)
-            if (!absent[c]) { org = fminf(org, lo[c][a]); top = fmaxf(top, hi[c][a]); }
-        if (absent[0] && absent[1]) { org = 0.0f; top = 0.0f; }
+        for (int k = 0; k < 4; ++k)
+            if (present[k]) { org = fminf(org, lo[k][a]); top = fmaxf(top, hi[k][a]); }
+        if (!(org <= top)) { org = 0.0f; top = 0.0f; }
         o.origin[a] = org;
         // smallest power of two `step` with decode(255) >= top; then every bound rounded outward and CHECKED with the
         // traversal's own decode expression
-        int e2 = 0;
+        int e2 = -126;
         const float ext = top - org;
-        if (ext > 0.0f) { (void)frexpf(ext / 255.0f, &e2); } else { e2 = -126; }
+        if (ext > 0.0f) (void)frexpf(ext / 255.0f, &e2);
         int be = e2 + 127;  // biased exponent of 2^e2
         be = be < 1 ? 1 : (be > 254 ? 254 : be);
         for (;;) {
             const float step = __uint_as_float((unsigned)be << 23);
             bool ok = true;
-            for (int c = 0; c < 2 && ok; ++c) {
-                unsigned ql = 255u, qh = 0u;  // an absent child: inverted, and flagged
-                if (!absent[c]) {
-                    float fl = floorf((lo[c][a] - org) / step), fh = ceilf((hi[c][a] - org) / step);
+            for (int k = 0; k < 4 && ok; ++k) {
+                unsigned ql = 255u, qh = 0u;  // an absent child: inverted (and its link says so)
+                if (present[k]) {
+                    float fl = floorf((lo[k][a] - org) / step), fh = ceilf((hi[k][a] - org) / step);
                     fl = fminf(fmaxf(fl, 0.0f), 255.0f);
                     fh = fminf(fmaxf(fh, 0.0f), 255.0f);
                     ql = (unsigned)fl; qh = (unsigned)fh;
-                    while (ql > 0u && pt_bvh_decode(ql, step, org) > lo[c][a]) --ql;
-                    while (qh < 255u && pt_bvh_decode(qh, step, org) < hi[c][a]) ++qh;
-                    if (pt_bvh_decode(ql, step, org) > lo[c][a] || pt_bvh_decode(qh, step, org) < hi[c][a]) ok = false;
+                    while (ql > 0u && pt_bvh_decode(ql, step, org) > lo[k][a]) --ql;
+                    while (qh < 255u && pt_bvh_decode(qh, step, org) < hi[k][a]) ++qh;
+                    if (pt_bvh_decode(ql, step, org) > lo[k][a] || pt_bvh_decode(qh, step, org) < hi[k][a]) ok = false;
                 }
-                o.q[6 * c + a] = (uint8_t)ql;
-                o.q[6 * c + 3 + a] = (uint8_t)qh;
+                o.q[6 * k + a] = (uint8_t)ql;
+                o.q[6 * k + 3 + a] = (uint8_t)qh;
             }
             if (ok || be >= 254) break;  // (be = 254 always suffices for finite boxes: 255 x 2^127 spans binary32)
             ++be;
         }
         ex[a] = (unsigned)be;
     }
-    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (flags << 24);
+    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+    for (int k = 0; k < 4; ++k) o.link[k] = link[k];
+    o.pad[0] = o.pad[1] = 0u;
     out[i] = o;
 }
 
 }  // namespace
 
-size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ntri - 1 : 0; }
+size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ptk_bvh_leaf_count(ntri) - 1 : 0; }
 
 size_t ptk_bvh_temp_bytes(int ntri)
 {
@@ -306,10 +342,10 @@ size_t ptk_bvh_temp_bytes(int ntri)
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
     const size_t n = (size_t)ntri;
     // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], cub temp
-    return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024 + sizeof(PtBvhNode) * n + 256;  // + the fp32 nodes
+    return 16 * n + 8 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024 + sizeof(PtBvhNode) * n + 512;  // + leaf keys, the fp32 nodes
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode32* nodes32, PtPrepTriangle* stris,
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode4* nodes4, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
@@ -317,6 +353,7 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     char* p = (char*)temp;
     unsigned long long* keys = (unsigned long long*)p; p += 8 * n;
     unsigned long long* sorted = (unsigned long long*)p; p += 8 * n;
+    unsigned long long* lkeys = (unsigned long long*)p; p += 8 * n;
     int* parent = (int*)p; p += 4 * 2 * n;
     int* right_child = (int*)p; p += 4 * n;
     int* flags = (int*)p; p += 4 * n;
@@ -337,9 +374,12 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipLaunchKernelGGL(pt_bvh_big_finish_kernel, dim3(1), dim3(1), 0, s, bounds, bigidx, prep, bigtab, nbig_dev);
     hipLaunchKernelGGL(pt_bvh_keys_kernel, grd, blk, 0, s, raw, ntri, bounds, keys);
     if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, grd, blk, 0, s, sorted, ntri, nodes, parent, right_child);
-    hipLaunchKernelGGL(pt_bvh_refit_kernel, grd, blk, 0, s, raw, sorted, ntri, bounds, nodes, parent, right_child, flags);
-    hipLaunchKernelGGL(pt_bvh_compress_kernel, grd, blk, 0, s, nodes, ntri, nodes32);
-    hipLaunchKernelGGL(pt_bvh_sorted_tris_kernel, grd, blk, 0, s, sorted, ntri, prep, stris);
+    const int shift = ptk_bvh_shift(ntri), nleaves = ptk_bvh_leaf_count(ntri);  // nleaves >= 2 (ntri >= 2)
+    const dim3 lgrd((nleaves + 255) / 256);
+    hipLaunchKernelGGL(pt_bvh_leaf_keys_kernel, lgrd, blk, 0, s, sorted, nleaves, shift, lkeys);
+    hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, lkeys, nleaves, nodes, parent, right_child);
+    hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, ntri, shift, nleaves, bounds, nodes, parent, right_child, flags);
+    hipLaunchKernelGGL(pt_bvh_collapse_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, nodes4);
+    hipLaunchKernelGGL(pt_bvh_leaf_tris_kernel, grd, blk, 0, s, sorted, ntri, prep, ltris);
     return hipGetLastError();
 }

@@ -34,24 +34,37 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
-// The node the trace kernel walks: 32 bytes = two 16-byte loads.  The search is bound by the CU's vector-memory
-// address path (every lane fetches its own node: 64 cache lines per load instruction), so bytes per node are what
-// count.  Both children's boxes are quantised to 8 bits per coordinate inside the node's own frame (origin =
-// lower corner of the children's union, one power-of-two step per axis), rounded OUTWARD and verified at build
-// time with the very expression the traversal decodes them with (fma(q, step, origin)): the decoded box contains
-// the fp32 box.  In Karras' numbering the two children of a node are always (gamma, gamma + 1) -- internal node
-// indices, or positions in the Morton-sorted triangle order for leaves -- so one index serves both.
-struct PtBvhNode32 {
+// The node the trace kernel walks: 64 bytes = one L2-miss transaction, FOUR children.  The search is bound by
+// the bytes its L2 misses pull in (profiles/r02/pmc_soup_lbvh_32B_nodes.txt: 46 % L2 hit rate, 3.9 TB/s of
+// 64-byte fetches of which a two-child 32-byte node used half), so a node is exactly one such fetch and all
+// of it is used: the binary radix tree is collapsed two levels at a time (every binary node at even depth
+// becomes a node whose children are its grandchildren, or a child that is a leaf), nodes keep their binary
+// indices (the odd levels' slots stay empty).  The children's boxes are quantised to 8 bits per coordinate in
+// the node's own frame (origin = lower corner of their union, one power-of-two step per axis), rounded
+// OUTWARD and verified at build time with the very expression the traversal decodes them with
+// (fma(q, step, origin)): the decoded box contains the fp32 box.
+struct PtBvhNode4 {
     float origin[3];
-    uint32_t meta;    // step exponents (biased as in binary32) x | y << 8 | z << 16, flags << 24
-    uint32_t gamma;   // left child = gamma, right child = gamma + 1
-    uint8_t q[12];    // left min xyz, left max xyz, right min xyz, right max xyz
+    uint32_t meta;      // step exponents (biased as in binary32) x | y << 8 | z << 16
+    uint32_t link[4];   // child k: node index, 0x80000000 | leaf, or PT_BVH_ABSENT
+    uint8_t q[24];      // child k: min xyz at q[6k], max xyz at q[6k + 3]
+    uint32_t pad[2];
 };
-static_assert(sizeof(PtBvhNode32) == 32, "compressed bvh node layout");
-#define PT_BVH_LEFT_LEAF 1u     // flags: the child is a triangle (position in the sorted order), not a node
-#define PT_BVH_RIGHT_LEAF 2u
-#define PT_BVH_LEFT_ABSENT 4u   // flags: nothing below this child can be hit (non-finite triangles, triangles kept
-#define PT_BVH_RIGHT_ABSENT 8u  //        out of the hierarchy)
+static_assert(sizeof(PtBvhNode4) == 64, "bvh node layout");
+#define PT_BVH_ABSENT 0xffffffffu  // nothing to visit in this slot (fewer than four children; non-finite triangles;
+                                   // triangles kept out of the hierarchy)
+
+// A LEAF of the hierarchy is a run of 1 << PT_BVH_CLUSTER_SHIFT consecutive triangles of the Morton order, walked
+// one triangle per step.  Leaf records are compact: 48 bytes, three 16-byte loads.
+#define PT_BVH_CLUSTER_SHIFT 0  // (2 = four triangles per leaf was measured: the 10^6-triangle soup's leaf boxes grow 9x in
+                                // cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s)
+#define PT_BVH_CLUSTER (1 << PT_BVH_CLUSTER_SHIFT)
+struct PtLeafTri {
+    float p1[3], e1[3], e2[3];  // as in PtPrepTriangle
+    uint32_t index;             // the triangle's index in the caller's buffer (ties in t go to the lowest)
+    float pad[2];
+};
+static_assert(sizeof(PtLeafTri) == 48, "leaf record layout");
 
 #define PT_TRACE_BATCH 256u    // largest number of samples per work-queue grab of a wave (PtTraceParams::batch)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
@@ -76,8 +89,10 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvhNode32* bvh;       // accel = BVH: ntri-1 internal nodes, root 0
-    const PtPrepTriangle* stris;  // accel = BVH: the prepared records in Morton-sorted (leaf) order, pad0[0] = triangle index
+    const PtBvhNode4* bvh;        // accel = BVH: four-child nodes at the binary tree's even-depth indices, root 0
+    const PtLeafTri* ltris;       // accel = BVH: the triangles in Morton-sorted order; leaf c holds [c << shift, (c + 1) << shift)
+    int32_t bvh_shift;            //              log2(triangles per leaf): PT_BVH_CLUSTER_SHIFT, or 0 for tiny scenes
+    int32_t bvh_leaves;           //              number of leaves; the hierarchy has bvh_leaves - 1 nodes, root 0
     const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
     const int32_t* bigidx;        //              their triangle indices, ascending
     int32_t nbig;
@@ -118,9 +133,11 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // prep: the prepared records of the same triangles.  bigtab[PT_BVH_BIG_MAX] / bigidx[PT_BVH_BIG_MAX] / *nbig_dev (device memory)
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
-// nodes[ntri-1] and stris[ntri] (device memory) receive the hierarchy the trace kernel walks
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode32* nodes, PtPrepTriangle* stris,
+// nodes[ptk_bvh_leaf_count(ntri) - 1] and ltris[ntri] (device memory) receive the hierarchy the trace kernel walks
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode4* nodes, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
+static inline int ptk_bvh_shift(int ntri) { return ntri >= 4 * PT_BVH_CLUSTER ? PT_BVH_CLUSTER_SHIFT : 0; }
+static inline int ptk_bvh_leaf_count(int ntri) { const int sh = ptk_bvh_shift(ntri); return (ntri + (1 << sh) - 1) >> sh; }
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);

@@ -1229,14 +1229,16 @@ void pt_trace_kernel(const PtTraceParams P)
 //   * per-lane stack: PT_BVH_LDS_STACK entries in LDS (entry-major: conflict-free), deeper ones in a private array;
 //   * the triangles the builder kept out of the hierarchy (pt_bvh.hip: the few that span the scene) are searched
 //     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
-//   * the search is bound by the CU's vector-memory address path (every lane fetches its own record: 64 cache
-//     lines per load instruction), so a node is 32 bytes = two loads (PtBvhNode32: 8-bit boxes in the node's own
-//     frame, conservative by construction), and a leaf reads 48 bytes of the Morton-sorted copy of the records;
+//   * the search is bound by the bytes its L2 misses fetch, so a node is one 64-byte line holding FOUR children
+//     (PtBvhNode4: the binary radix tree collapsed two levels at a time, 8-bit boxes in the node's own frame,
+//     conservative by construction), visited nearest first; a leaf is a 48-byte record of the Morton-sorted copy
+//     of the triangles;
 //   * every link is visited at most once; a step budget and index checks make a damaged hierarchy end the
 //     search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
 // triangles tested (both per lane), traversal steps of the waves.  Never the timed kernel.
-#define PT_BVH_STACK 64        // a radix tree over 64-bit keys has at most 64 levels
+#define PT_BVH_STACK 96        // a radix tree over 64-bit keys has at most 64 levels = 32 levels of four-child nodes,
+                               // each of which stacks at most three children
 #define PT_BVH_LDS_STACK 24
 #ifndef PT_BVH_REFILL
 #define PT_BVH_REFILL 40
@@ -1281,7 +1283,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
     const int ntri = P.ntri;
-    const unsigned n_nodes = (unsigned)ntri - 1u;
+    const unsigned n_nodes = (unsigned)P.bvh_leaves - 1u;
+    const unsigned shift = (unsigned)P.bvh_shift, tmask = (1u << shift) - 1u;
     const unsigned DONE = 0x7fffffffu;  // (an internal-node link this large cannot exist)
     // LDS: the table of the triangles outside the hierarchy (pass 2 fetches its records per lane: pt_fetch_rec), the
     // stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
@@ -1317,7 +1320,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     // the search's state
     float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
     int hidx = -1;
-    unsigned cur = DONE;   // a link: internal node index, or 0x80000000 | triangle
+    unsigned cur = DONE;   // a link: internal node index, or 0x80000000 | position in the sorted order (a leaf is walked
+                           // one triangle per step: leaf c starts at position c << shift)
     int sp = 0;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f;
     unsigned budget = 0u;
@@ -1362,46 +1366,58 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 sp = 0;
             } else if (leaf) {
                 if (TALLY) ++c_leaves;
-                const float4* qp = reinterpret_cast<const float4*>(P.stris + idx);
+                const float4* qp = reinterpret_cast<const float4*>(P.ltris + idx);
                 const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
                 PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
                 r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
                 r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
                 r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
                 pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), s.o, s.d, tmax, hu, hv, hidx);
+                // the leaf's next triangle, if it has one
+                if ((idx & tmask) != tmask && idx + 1u < (unsigned)ntri) { next = cur + 1u; pop = false; }
             } else {
                 if (TALLY) ++c_nodes;
                 const uint4* np = reinterpret_cast<const uint4*>(P.bvh + idx);
-                const uint4 w0 = np[0], w1 = np[1];
+                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-                const unsigned meta = w0.w, flags = meta >> 24;
+                const unsigned meta = w0.w;
                 const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
                             sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-                // decode exactly as pt_bvh_compress_kernel verified: fma(q, step, origin)
-                float4 lmin, lmax, rmin, rmax;
-                lmin.x = pt_fma((float)(w1.y & 255u), sx, ox);         lmin.y = pt_fma((float)((w1.y >> 8) & 255u), sy, oy);
-                lmin.z = pt_fma((float)((w1.y >> 16) & 255u), sz, oz); lmax.x = pt_fma((float)(w1.y >> 24), sx, ox);
-                lmax.y = pt_fma((float)(w1.z & 255u), sy, oy);         lmax.z = pt_fma((float)((w1.z >> 8) & 255u), sz, oz);
-                rmin.x = pt_fma((float)((w1.z >> 16) & 255u), sx, ox); rmin.y = pt_fma((float)(w1.z >> 24), sy, oy);
-                rmin.z = pt_fma((float)(w1.w & 255u), sz, oz);         rmax.x = pt_fma((float)((w1.w >> 8) & 255u), sx, ox);
-                rmax.y = pt_fma((float)((w1.w >> 16) & 255u), sy, oy); rmax.z = pt_fma((float)(w1.w >> 24), sz, oz);
-                const unsigned link_l = w1.x | ((flags & PT_BVH_LEFT_LEAF) ? 0x80000000u : 0u);
-                const unsigned link_r = (w1.x + 1u) | ((flags & PT_BVH_RIGHT_LEAF) ? 0x80000000u : 0u);
-                float tl_, tr_;
-                const bool hit_l = pt_slab(lmin, lmax, s.o, ix, iy, iz, tmax, tl_) & !(flags & PT_BVH_LEFT_ABSENT);
-                const bool hit_r = pt_slab(rmin, rmax, s.o, ix, iy, iz, tmax, tr_) & !(flags & PT_BVH_RIGHT_ABSENT);
-                if (hit_l & hit_r) {
-                    const bool left_first = tl_ <= tr_;
-                    const unsigned far = left_first ? link_r : link_l;
-                    if (sp < PT_BVH_LDS_STACK) stk[sp * PT_TRACE_THREADS] = far;
-                    else if (sp < PT_BVH_STACK) ovf[sp - PT_BVH_LDS_STACK] = far;
-                    sp = sp < PT_BVH_STACK ? sp + 1 : sp;
-                    next = left_first ? link_l : link_r;
-                    pop = false;
-                } else if (hit_l | hit_r) {
-                    next = hit_l ? link_l : link_r;
-                    pop = false;
+                // the four children: boxes decoded exactly as pt_bvh_collapse_kernel verified (fma(q, step, origin)),
+                // entry distance +Inf for a child that is absent or missed
+                const unsigned qw[6] = { w2.x, w2.y, w2.z, w2.w, w3.x, w3.y };  // 24 bytes: child k at bytes 6k .. 6k+5
+                unsigned lk[4] = { w1.x, w1.y, w1.z, w1.w };
+                float tk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // byte j of the 24 (little endian): (qw[j >> 2] >> (8 * (j & 3))) & 255
+                    float4 bmin, bmax;
+                    bmin.x = pt_fma((float)((qw[(6 * k + 0) >> 2] >> (8 * ((6 * k + 0) & 3))) & 255u), sx, ox);
+                    bmin.y = pt_fma((float)((qw[(6 * k + 1) >> 2] >> (8 * ((6 * k + 1) & 3))) & 255u), sy, oy);
+                    bmin.z = pt_fma((float)((qw[(6 * k + 2) >> 2] >> (8 * ((6 * k + 2) & 3))) & 255u), sz, oz);
+                    bmax.x = pt_fma((float)((qw[(6 * k + 3) >> 2] >> (8 * ((6 * k + 3) & 3))) & 255u), sx, ox);
+                    bmax.y = pt_fma((float)((qw[(6 * k + 4) >> 2] >> (8 * ((6 * k + 4) & 3))) & 255u), sy, oy);
+                    bmax.z = pt_fma((float)((qw[(6 * k + 5) >> 2] >> (8 * ((6 * k + 5) & 3))) & 255u), sz, oz);
+                    bmin.w = bmax.w = 0.0f;
+                    float tn;
+                    const bool hit = pt_slab(bmin, bmax, s.o, ix, iy, iz, tmax, tn) & (lk[k] != PT_BVH_ABSENT);
+                    tk[k] = hit ? tn : __builtin_inff();
                 }
+                // nearest first: sort the four (distance, link) pairs (5 compare-exchanges; misses sink to the end) ...
+#define PT_CE(a, b) { const bool sw = tk[b] < tk[a]; const float ta_ = sw ? tk[b] : tk[a], tb_ = sw ? tk[a] : tk[b]; \
+                      const unsigned la_ = sw ? lk[b] : lk[a], lb_ = sw ? lk[a] : lk[b]; tk[a] = ta_; tk[b] = tb_; lk[a] = la_; lk[b] = lb_; }
+                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+                // ... go to the nearest, stack the others farthest first
+#pragma unroll
+                for (int k = 3; k >= 1; --k) {
+                    if (tk[k] < __builtin_inff()) {
+                        if (sp < PT_BVH_LDS_STACK) stk[sp * PT_TRACE_THREADS] = lk[k];
+                        else if (sp < PT_BVH_STACK) ovf[sp - PT_BVH_LDS_STACK] = lk[k];
+                        sp = sp < PT_BVH_STACK ? sp + 1 : sp;
+                    }
+                }
+                if (tk[0] < __builtin_inff()) { next = lk[0]; pop = false; }
             }
             if (pop && sp > 0) {
                 --sp;

@@ -98,8 +98,8 @@ struct pt_device_s {
     int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
                                 // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
-    PtBvhNode32* bvh;           // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
-    PtPrepTriangle* stris;      // its leaves: the prepared records in Morton order
+    PtBvhNode4* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
+    PtLeafTri* ltris;           // its leaves: the triangles in Morton order
     PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
     int* bigidx;
     int nbig;
@@ -249,7 +249,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->prep) hipFree(d->prep);
     if (d->p1tab) hipFree(d->p1tab);
     if (d->bvh) hipFree(d->bvh);
-    if (d->stris) hipFree(d->stris);
+    if (d->ltris) hipFree(d->ltris);
     if (d->rad) hipFree(d->rad);
     if (d->pmask) hipFree(d->pmask);
     if (d->counters) hipFree(d->counters);
@@ -692,8 +692,8 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         if (d->prep) hipFree(d->prep);
         if (d->p1tab) hipFree(d->p1tab);
         if (d->bvh) hipFree(d->bvh);
-        if (d->stris) hipFree(d->stris);
-        d->stris = nullptr;
+        if (d->ltris) hipFree(d->ltris);
+        d->ltris = nullptr;
         d->prep = nullptr;
         d->p1tab = nullptr;
         d->bvh = nullptr;
@@ -750,15 +750,15 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 {
     if (d->bvh_valid) return PT_OK;
     if (!d->bvh) {
-        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvhNode32));
-        if (e == hipSuccess) e = hipMalloc(&d->stris, d->prep_capacity * sizeof(PtPrepTriangle));
+        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvhNode4));
+        if (e == hipSuccess) e = hipMalloc(&d->ltris, d->prep_capacity * sizeof(PtLeafTri));
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e)); }
     }
     const size_t temp_bytes = ptk_bvh_temp_bytes(ntri);
     void* temp = nullptr;
     hipError_t e = hipMalloc(&temp, temp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH build workspace allocation failed: %s", hipGetErrorString(e)); }
-    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->stris, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, temp, temp_bytes,
+    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->ltris, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, temp, temp_bytes,
                       d->stream);
     int nbig = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&nbig, d->bigidx + PT_BVH_BIG_MAX, sizeof nbig, hipMemcpyDeviceToHost, d->stream);
@@ -896,7 +896,9 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
-        tp.stris = d->stris;
+        tp.ltris = d->ltris;
+        tp.bvh_shift = ptk_bvh_shift(rp.num_triangles);
+        tp.bvh_leaves = ptk_bvh_leaf_count(rp.num_triangles);
         tp.bigtab = d->bigtab;
         tp.bigidx = d->bigidx;
         tp.nbig = use_bvh ? d->nbig : 0;
