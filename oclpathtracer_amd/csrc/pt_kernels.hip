@@ -317,10 +317,17 @@ PTK_DEV pt_lanes pt_tri_pass1(const PtTriRec& r, const f3& o, const f3& d)
 // dynamic LDS of the trace kernels: the workgroup's copy of the hot triangle records
 extern __shared__ __attribute__((aligned(16))) float pt_lds_tab[];
 
-// record i for pass 2: from the LDS copy (stride PT_LDS_TRI_STRIDE dwords, 32-bit LDS addressing)
-// or, for scenes too large for it, from the prepared table in global memory (stride 16)
-template <bool LDS_TABLE>
-PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
+// record i for pass 2.  LDS_TABLE selects where the records of a scene live for the per-lane fetches:
+//   1  the whole prepared table is copied to LDS once per workgroup (scenes up to PT_LDS_TRI_MAX triangles);
+//      i = triangle index, lds_off = 0
+//   2  TILED: a larger scene searched by brute force streams the records of the current 32-triangle chunk into a
+//      per-wave LDS tile when many lanes have survivors in it (pt_stage_tile); i = index inside the chunk,
+//      lds_off = the wave's tile
+//   0  per-lane loads from the prepared table in global memory (stride 16 dwords); i = triangle index
+// (LDS: stride PT_LDS_TRI_STRIDE dwords, 32-bit LDS addressing; per-lane global loads of a small table saturate
+// the CU's vector-memory address path: every lane is its own cache line.)
+template <int LDS_TABLE>
+PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i, unsigned lds_off = 0u)
 {
     float4 q0, q1;
     float e2z;
@@ -330,7 +337,7 @@ PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
         typedef __attribute__((address_space(3))) const float pt_lds_f32;
         typedef float pt_v4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) const pt_v4 pt_lds_f32x4;
-        pt_lds_f32* t = (pt_lds_f32*)pt_lds_tab + __umul24((unsigned)i, (unsigned)PT_LDS_TRI_STRIDE);  // i <= 256
+        pt_lds_f32* t = (pt_lds_f32*)pt_lds_tab + lds_off + __umul24((unsigned)i, (unsigned)PT_LDS_TRI_STRIDE);  // i <= 256
         const pt_v4 a = *(pt_lds_f32x4*)t, b = *(pt_lds_f32x4*)(t + 4);
         q0 = make_float4(a.x, a.y, a.z, a.w);
         q1 = make_float4(b.x, b.y, b.z, b.w);
@@ -346,6 +353,21 @@ PTK_DEV PtTriRec pt_fetch_rec(const PtPrepTriangle* tris, int i)
     r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
     r.e2x = q1.z; r.e2y = q1.w; r.e2z = e2z;
     return r;
+}
+
+// TILED mode: the records of chunk [base, base + n) into this wave's LDS tile (12 of each record's 16 dwords)
+PTK_DEV void pt_stage_tile(const PtPrepTriangle* tris, int base, int n, unsigned tile_off, unsigned lane)
+{
+    const float* g = reinterpret_cast<const float*>(tris + base);
+    for (unsigned k = lane; k < (unsigned)n * PT_LDS_TRI_STRIDE; k += 64u) {
+        const unsigned tri = k / PT_LDS_TRI_STRIDE, w = k - tri * PT_LDS_TRI_STRIDE;
+        pt_lds_tab[tile_off + k] = g[tri * 16u + w];
+    }
+    // the wave's own LDS writes, read back by other lanes of the same wave: program order suffices for the
+    // hardware (one in-order LDS queue per wave); this keeps the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <bool DET_BOUNDED>
@@ -399,6 +421,7 @@ struct PtTail {
     pt_lds_u64* keys;  // [64]  best (t bits << 32 | triangle) the tail found for the ray of each lane; ~0 = none
     pt_lds_u32* list;  // [PT_TAIL_LIST]  pending pairs: triangle << 6 | ray lane  (ring)
     unsigned wr, rd;   // wave-uniform ring positions
+    unsigned tile;     // TILED mode (pt_fetch_rec): dword offset of this wave's record tile in LDS
 };
 
 // the reference's test of one (ray, triangle) pair without the running tmax: passes :100,:109,:117 and 0 < t < 1e20
@@ -431,7 +454,7 @@ PTK_DEV float pt_from_lane(unsigned byte_addr, float v)
 
 // test the first `cnt` (<= 64) pending pairs, one per lane; every lane of the wave takes part (the rays travel by
 // ds_bpermute, which needs their owners' lanes enabled)
-template <bool DET_BOUNDED, bool LDS_TABLE>
+template <bool DET_BOUNDED, int LDS_TABLE>
 PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrepTriangle* tris, const f3& o, const f3& d)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -443,7 +466,7 @@ PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrep
     const unsigned a = ray << 2;
     const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
     const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
-    const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, (int)tri);
+    const PtTriRec r = pt_fetch_rec<(LDS_TABLE == 1 ? 1 : 0)>(tris, (int)tri);  // (a pending pair may be of an earlier chunk than the tile's)
     float t;
     const bool ok = pt_tri_candidate<DET_BOUNDED>(r, po, pd, t) & act;
     if (ok) {
@@ -454,22 +477,23 @@ PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrep
 }
 
 // pass 2 of one 32-triangle chunk whose survivor mask is m (bit n-1-j <-> triangle base + j)
-template <bool DET_BOUNDED, bool LDS_TABLE>
+template <bool DET_BOUNDED, int LDS_TABLE>
 PTK_DEV void pt_pass2_chunk(unsigned m, int base, int n, const PtPrepTriangle* tris, const f3& o, const f3& d, float& tmax, float& hu,
                             float& hv, int& hidx, PtTail& tl, unsigned lane, unsigned& steps)
 {
     // own steps: every lane tests its next survivor (index 0 and ok = false once it has none left),
     // while more than PT_TAIL_LANES lanes still hold one
+    if (LDS_TABLE == 2 && (unsigned)__popcll(PT_LANES(m != 0u)) > (unsigned)PT_TAIL_LANES) pt_stage_tile(tris, base, n, tl.tile, lane);
     for (pt_lanes more = PT_LANES(m != 0u); (unsigned)__popcll(more) > (unsigned)PT_TAIL_LANES; more = PT_LANES(m != 0u)) {
         ++steps;
         const bool valid = m != 0u;
         unsigned lz;  // leading zeros: the highest bit is the lowest triangle index (-1 for m = 0)
         asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
-        // (a lane without survivors forms a wild index: harmless for the LDS table -- out-of-range
+        // (a lane without survivors forms a wild index: harmless for the LDS copies -- out-of-range
         // LDS reads return 0 -- and its result is discarded; the global table needs a real address)
-        const int i = (LDS_TABLE || valid) ? base + n - 32 + (int)lz : base;
+        const int i = (LDS_TABLE != 0 || valid) ? base + n - 32 + (int)lz : base;
         m &= ~(0x80000000u >> (lz & 31u));
-        const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+        const PtTriRec r = LDS_TABLE == 2 ? pt_fetch_rec<2>(tris, n - 32 + (int)lz, tl.tile) : pt_fetch_rec<LDS_TABLE>(tris, i);
         pt_tri_pass2<DET_BOUNDED>(r, i, valid, o, d, tmax, hu, hv, hidx);
     }
     // the rest of this chunk's survivors join the wave's pending pairs
@@ -492,7 +516,7 @@ PTK_DEV void pt_pass2_chunk(unsigned m, int base, int n, const PtPrepTriangle* t
 }
 
 // end of a search: the pending pairs, then the merge of what the tail found
-template <bool DET_BOUNDED, bool LDS_TABLE>
+template <bool DET_BOUNDED, int LDS_TABLE>
 PTK_DEV void pt_pass2_finish(const PtPrepTriangle* tris, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx,
                              PtTail& tl, unsigned lane, unsigned& steps)
 {
@@ -513,8 +537,8 @@ PTK_DEV void pt_pass2_finish(const PtPrepTriangle* tris, const f3& o, const f3& 
             const bool better = (key != ~0ull) & ((kt < tmax) | ((kt == tmax) & (ki < hidx)));
             if (PT_LANES(better) != 0ull) {
                 ++steps;
-                const int i = (LDS_TABLE || better) ? ki : 0;
-                const PtTriRec r = pt_fetch_rec<LDS_TABLE>(tris, i);
+                const int i = (LDS_TABLE == 1 || better) ? ki : 0;
+                const PtTriRec r = pt_fetch_rec<(LDS_TABLE == 1 ? 1 : 0)>(tris, i);
                 float tm = better ? 1e20f : tmax;  // (a lane that is not `better` must keep its own result: valid = false)
                 pt_tri_pass2<DET_BOUNDED>(r, i, better, o, d, tm, hu, hv, hidx);
                 tmax = tm;
@@ -612,7 +636,7 @@ PTK_DEV void pt_quad3_pass1(pt_const_f32p t, const PtRay3& r, pt_f2& un, pt_f2& 
 #endif
 
 // QUADS: 0 = independent triangles (pt_tri_pass1), 3 = packed shared-u filter (pt_quad3_pass1)
-template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
+template <bool DET_BOUNDED, int LDS_TABLE, int QUADS>
 PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d,
                                        bool alive, float& tmax, float& hu, float& hv, int& hidx,
                                        float delta1, float ray_radius, pt_const_f32p p1tab, float p1_lo, float p1_hi,
@@ -731,7 +755,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
 
 // closest hit of a FRESH wave of primary rays whose pixels have candidate masks (pt_primary_mask_kernel):
 // pass 1 is skipped, pass 2 is the one of pt_intersect_two_pass.  ntri <= 64 (two chunks).
-template <bool DET_BOUNDED, bool LDS_TABLE>
+template <bool DET_BOUNDED, int LDS_TABLE>
 PTK_DEV unsigned pt_intersect_primary(pt_const_f32p T, const PtPrepTriangle* tris, int ntri, const f3& o, const f3& d, bool alive,
                                       float& tmax, float& hu, float& hv, int& hidx, uint2 pm, PtTail tl, unsigned lane,
                                       unsigned long long* vstat = nullptr)
@@ -1096,13 +1120,13 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
     return count == 64u;
 }
 
-template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
+template <bool DET_BOUNDED, int LDS_TABLE, int QUADS>
 PTK_DEV void pt_trace_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
     pt_const_f32p T = (pt_const_f32p)(const float*)P.tris;
     const int ntri = P.ntri;
-    if (LDS_TABLE) {
+    if (LDS_TABLE == 1) {
         const float* g = reinterpret_cast<const float*>(P.tris);
         for (int k = (int)threadIdx.x; k < ntri * PT_LDS_TRI_STRIDE; k += PT_TRACE_THREADS) {
             int tri = k / PT_LDS_TRI_STRIDE, w = k - tri * PT_LDS_TRI_STRIDE;
@@ -1111,16 +1135,17 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         __syncthreads();
     }
     // this wave's pool of parked paths, behind the triangle table (ptk_trace_lds_bytes)
-    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * (4 * PT_POOL);
+    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * (4 * PT_POOL);
     unsigned pool_n = 0u;                    // parked paths (wave-uniform)
     // this wave's pass-2 tail: 64 key slots + the pending-pair ring, behind the four pools
     PtTail tl;
     {
-        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + (LDS_TABLE ? ntri * PT_LDS_TRI_STRIDE : 0) + (PT_TRACE_THREADS / 64) * (16 * PT_POOL) +
-                        (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
+        const unsigned tails = (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + (PT_TRACE_THREADS / 64) * (16 * PT_POOL);
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + tails + (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
+        tl.tile = tails + (PT_TRACE_THREADS / 64) * (128u + PT_TAIL_LIST) + (threadIdx.x >> 6) * (32u * PT_LDS_TRI_STRIDE);  // (TILED mode only)
         tl.keys[lane] = ~0ull;
     }
 
@@ -1214,7 +1239,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 7
 #endif
-template <bool DET_BOUNDED, bool LDS_TABLE, int QUADS>
+template <bool DET_BOUNDED, int LDS_TABLE, int QUADS>
 __global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
 void pt_trace_kernel(const PtTraceParams P)
 {
@@ -1308,6 +1333,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
+        tl.tile = 0u;
         tl.keys[lane] = ~0ull;
     }
     pt_const_f32p bigT = (pt_const_f32p)(const float*)P.bigtab;
@@ -1341,7 +1367,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (P.nbig > 0) {
                     // the triangles outside the hierarchy, in ascending index order; hp = position in their table
                     int hp = -1;
-                    pt_intersect_two_pass<DET_BOUNDED, true, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
+                    pt_intersect_two_pass<DET_BOUNDED, 1, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
                                                                  nullptr, 0.0f, 0.0f, tl, lane);
                     if (start && hp >= 0) hidx = P.bigidx[hp];
                 }
@@ -1612,15 +1638,15 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
     if (p.ntri <= PT_LDS_TRI_MAX) {
         const size_t lds = ptk_trace_lds_bytes(p.ntri);
         if (det_bounded && quads == 3)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            hipLaunchKernelGGL((pt_trace_kernel<true, 1, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else if (det_bounded)
-            hipLaunchKernelGGL((pt_trace_kernel<true, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            hipLaunchKernelGGL((pt_trace_kernel<true, 1, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         else
-            hipLaunchKernelGGL((pt_trace_kernel<false, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            hipLaunchKernelGGL((pt_trace_kernel<false, 1, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
         const size_t lds = ptk_trace_lds_bytes(p.ntri);
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, 2, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((pt_trace_kernel<false, 2, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     }
     return hipGetLastError();
 }
@@ -1667,7 +1693,9 @@ size_t ptk_trace_lds_bytes(int ntri)
 {
     const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
     // per wave: the pool of parked paths (PT_POOL x 64 B) + the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
-    return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL * 4 * sizeof(float4) + 64 * 8 + PT_TAIL_LIST * 4);
+    // + for scenes too large for the table, the record tile of the current chunk (32 x 48 B)
+    const size_t tile = ntri <= PT_LDS_TRI_MAX ? 0 : (size_t)32 * PT_LDS_TRI_STRIDE * sizeof(float);
+    return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL * 4 * sizeof(float4) + 64 * 8 + PT_TAIL_LIST * 4 + tile);
 }
 
 size_t ptk_trace_bvh_lds_bytes(void)
@@ -1687,7 +1715,7 @@ int ptk_trace_bvh_blocks_per_cu(void)
 int ptk_trace_blocks_per_cu(int ntri)
 {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, true, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, 1, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

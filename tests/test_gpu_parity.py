@@ -346,6 +346,36 @@ def test_kernel_specialisations_match_oracle(device, oracle, kind, quad_filter):
     assert gst["rays"] == st["rays"]
 
 
+@pytest.mark.parametrize("copies", [8, 13])
+def test_tiled_brute_force_between_the_lds_table_and_the_lbvh(device, oracle, cornell, copies):
+    """Scenes of 257 ... 511 triangles are searched by brute force with the records of the current 32-triangle chunk
+    streamed through a per-wave LDS tile (north_star's "LDS staging of triangle tiles"; the reference's loop is
+    GenerateColors.cl:137-154 with a runtime count).  Nested, shrunk copies of the Cornell box make MANY lanes hold
+    survivors in most chunks, so the tile path (not just the tail) does the work: 288 and 468 triangles."""
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    parts = []
+    for c in range(copies):
+        t = tris.copy()
+        k = np.float32(1.0 - 0.06 * c)
+        for f in ("p1", "p2", "p3"):
+            t[f][:, :3] = t[f][:, :3] * k + np.array([0.0, 2.7, -2.8], np.float32) * (np.float32(1.0) - k)
+        parts.append(t)
+    big = np.concatenate(parts)
+    assert 256 < len(big) < 512
+    W, H, frames = 64, 48, 3
+    want, st = oracle.render(big, mats, W, H, frames, want_stats=True)
+    r = Renderer(device, big, mats, W, H, want_stats=True)
+    try:
+        r.render(frames)
+        got, gst = r.read(), r.read_stats()
+    finally:
+        r.release()
+    assert_fb_equal(got, want, "tiled brute force, %d triangles" % len(big))
+    assert gst["rays"] == st["rays"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,ntri", [("cornell", 36), ("soup", 300), ("soup", 2000), ("soup", 20000), ("degenerate", 36),
                                         ("pairs_broken", 36), ("quads_far", 36)])
