@@ -3,7 +3,7 @@
 # usage: tools/gpu_pmc.sh <tag> [spp]   -> gpurun_out/pmc_<tag>_<pass>/
 set -o pipefail
 TAG=${1:-r01}
-SPP=${2:-64}
+SPP=${2:-256}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 run_pass () {
