@@ -74,7 +74,7 @@ static_assert(sizeof(PtLeafTri) == 48, "leaf record layout");
 struct PtTraceParams {
     const PtPrepTriangle* tris;
     const PtRawMaterial* mats;
-    float4* rad;                  // [chunk_frames][npix_local] path radiance (max(L,0), w unused)
+    float* rad;                   // [chunk_frames][npix_local][3] path radiance max(L,0), 12 bytes per sample
     unsigned int* batch_counter;  // zeroed before the launch
     unsigned long long* stats;    // may be null: [0] samples, [1] rays
     int32_t width, height;
@@ -101,7 +101,7 @@ struct PtTraceParams {
 };
 
 struct PtFoldParams {
-    const float4* rad;  // [frame_count][npix_local]
+    const float* rad;   // [frame_count][npix_local][3]
     float4* fb;         // [npix_local] gamma-encoded running mean (GenerateColors.cl:314-321)
     uint32_t npix_local;
     int32_t frame_begin, frame_count;

@@ -967,16 +967,18 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         }
     }
     if (finished) {
-        // :260.  One ALIGNED 16-byte store per sample (w = 1 is never read: the fold rewrites it).  Staging three
-        // floats instead (12 bytes, measured: profiles/r02/pmc_r02_rad12.txt) RAISED the HBM traffic of this kernel
-        // from 22.3 to 35.2 bytes per sample: stores that straddle 32-byte sectors turn into read-modify-writes
-        // when a partly filled line leaves the L2.
-        float4 out;
-        out.x = pt_max(s.L.x, 0.0f);
-        out.y = pt_max(s.L.y, 0.0f);
-        out.z = pt_max(s.L.z, 0.0f);
-        out.w = 1.0f;
-        P.rad[(size_t)s.fl * P.npix_local + s.lp] = out;
+        // :260; the w lane of the reference's float4 is overwritten with 1.0 by gammaCorrect (:293) and never read
+        // before: three floats per sample are staged, not four (measured at the full 256 spp, profiles/r02/
+        // pmc_r02_summary.txt: 35.2 bytes of HBM traffic per sample against 41.0 with aligned 16-byte records --
+        // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
+        // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
+        float* out = P.rad + ((size_t)s.fl * P.npix_local + s.lp) * 3u;
+        typedef float pt_f3v __attribute__((ext_vector_type(3)));
+        pt_f3v v;
+        v.x = pt_max(s.L.x, 0.0f);
+        v.y = pt_max(s.L.y, 0.0f);
+        v.z = pt_max(s.L.z, 0.0f);
+        *reinterpret_cast<pt_f3v*>(out) = v;  // one 12-byte store
         n_samples++;
         alive = false;
     }
@@ -1506,9 +1508,9 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
     float m = 0.0f;
     int z = P.frame_begin;
     if (z != 0) m = *fbp;
-    const float* radp = reinterpret_cast<const float*>(P.rad + lp) + ch;
+    const float* radp = P.rad + (size_t)lp * 3u + ch;  // == P.rad + tid: consecutive lanes read consecutive floats
     for (int f = 0; f < P.frame_count; ++f, ++z) {
-        const float c = radp[(size_t)f * P.npix_local * 4u];
+        const float c = radp[(size_t)f * P.npix_local * 3u];
         if (z == 0) {
             m = pt_pow(c, inv_gamma, LC, LL, ET);
         } else {

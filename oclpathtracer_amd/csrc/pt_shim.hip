@@ -109,7 +109,7 @@ struct pt_device_s {
     float prep_p1_lo, prep_p1_hi;
     unsigned int* det_bound_dev;  // PT_PREP_WORDS device words written by the prep kernel
     // fused-render workspace
-    float4* rad;             // radiance staging: 16 bytes per (frame, pixel) of a chunk
+    float* rad;              // radiance staging: 12 bytes per (frame, pixel) of a chunk
     size_t rad_bytes;
     uint2* pmask;            // primary-ray candidate masks of the local pixels (pt_primary_mask_kernel)
     size_t pmask_pixels;
@@ -811,26 +811,26 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
                          (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
     if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
 
-    // frames per chunk: radiance staging is 16 B x pixels x frames
+    // frames per chunk: radiance staging is 12 B x pixels x frames
     // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
     // take the whole call: a steady-state render loop makes no runtime query at all)
     uint64_t budget = d->rad_bytes;
-    if ((uint64_t)rp.frame_count * npix * 16 > budget) {
+    if ((uint64_t)rp.frame_count * npix * 12 > budget) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 16);
+        budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 12);
         budget = std::min<uint64_t>(budget, (uint64_t)free_b / 2 + d->rad_bytes);
         budget = std::max<uint64_t>(budget, d->rad_bytes);
     }
-    int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 16)));
+    int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 12)));
     if (d->opt_chunk > 0) chunk = (int)std::min<int64_t>(chunk, d->opt_chunk);
     int nchunks = (rp.frame_count + chunk - 1) / chunk;
     if (nchunks > PT_MAX_CHUNKS) {
         chunk = (rp.frame_count + PT_MAX_CHUNKS - 1) / PT_MAX_CHUNKS;
         nchunks = (rp.frame_count + chunk - 1) / chunk;
-        if ((uint64_t)chunk * npix * 16 > budget) return fail(PT_ERR_OOM, "not enough device memory for radiance staging");
+        if ((uint64_t)chunk * npix * 12 > budget) return fail(PT_ERR_OOM, "not enough device memory for radiance staging");
     }
-    size_t need = (size_t)chunk * npix * sizeof(float4);
+    size_t need = (size_t)chunk * npix * 12;
     if (d->rad_bytes < need) {
         HIP_TRY(hipStreamSynchronize(d->stream));
         if (d->rad) hipFree(d->rad);
