@@ -34,6 +34,20 @@ PTK_DEV unsigned pt_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_
 // number of set bits of m below this lane's position
 PTK_DEV unsigned pt_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
+// The trace kernels' argument block, RE-READ where it is used.  Passed by value, PtTraceParams lands in ~40 SGPRs at
+// kernel entry and stays live through the bounce loop; at 7 waves per SIMD the compiler then spills SGPRs to VGPR
+// lanes and pays v_readlane_b32 -- VALU issue slots, the resource this kernel is bound by -- in every bounce (24 per
+// bounce before this).  The fields that only regeneration and shading need are instead loaded from the kernarg
+// segment at their point of use: s_load on the scalar memory pipe, nothing live in between.  (The empty asm makes the
+// pointer opaque so the loads are not hoisted back out of the loop.)
+typedef const __attribute__((address_space(4))) PtTraceParams* pt_kargs_p;
+PTK_DEV pt_kargs_p pt_kargs()
+{
+    pt_kargs_p k = (pt_kargs_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 // camera position, GenerateColors.cl:265
 #define PT_EYE_X 0.0f
 #define PT_EYE_Y 2.75f
@@ -858,6 +872,7 @@ template <bool DET_BOUNDED>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
                       unsigned& n_rays, unsigned& n_samples, unsigned long long* sub = nullptr)
 {
+    const pt_kargs_p K = pt_kargs();  // tris, mats, nmat, max_bounces, rad, npix_local: read here, not kept in SGPRs
 #if PT_STAMPS == 2
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
 #define PT_SUB(var) PT_STAMP(var)
@@ -886,15 +901,15 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
 
         // deferred HitRecord of the closest hit (:127-130): same values as writing it at every
         // acceptance, only the last one is read.
-        const float4 nid = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(P.tris + hidx) + 12);
+        const float4 nid = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(K->tris + hidx) + 12);
         const f3 N = mk3(nid.x, nid.y, nid.z);
         int mid = __float_as_int(nid.w);
-        mid = mid < 0 ? 0 : (mid >= P.nmat ? P.nmat - 1 : mid);  // never fault on a corrupt id
+        mid = mid < 0 ? 0 : (mid >= K->nmat ? K->nmat - 1 : mid);  // never fault on a corrupt id
         f3 p = add3(s.o, scale3(s.d, tmax));
         float w = 1.0f - hu - hv;
         f3 n = normalize3(add3(add3(scale3(N, hu), scale3(N, hv)), scale3(N, w)));
 
-        const PtRawMaterial* mat = P.mats + mid;  // :239
+        const PtRawMaterial* mat = K->mats + mid;  // :239
         const float4 alb = *reinterpret_cast<const float4*>(mat->albedo);
         const float4 emi = *reinterpret_cast<const float4*>(mat->emissive);
         const float rough = mat->roughness;
@@ -958,7 +973,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
             s.mask.y = s.mask.y * (color.y * dwin / pdf);
             s.mask.z = s.mask.z * (color.z * dwin / pdf);
             s.bounce++;
-            if (s.bounce >= P.max_bounces) {
+            if (s.bounce >= K->max_bounces) {
                 finished = true;
             } else {
                 s.o = add3(p, scale3(wi, 0.01f));  // :257
@@ -972,7 +987,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         // pmc_r02_summary.txt: 35.2 bytes of HBM traffic per sample against 41.0 with aligned 16-byte records --
         // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
         // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
-        float* out = P.rad + ((size_t)s.fl * P.npix_local + s.lp) * 3u;
+        float* out = K->rad + ((size_t)s.fl * K->npix_local + s.lp) * 3u;
         typedef float pt_f3v __attribute__((ext_vector_type(3)));
         pt_f3v v;
         v.x = pt_max(s.L.x, 0.0f);
@@ -1028,18 +1043,19 @@ struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, en
 // when the current one is used up; false when there is nothing left
 PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q)
 {
+    const pt_kargs_p K = pt_kargs();
     if (q.pix != q.end) return true;
     if (q.exhausted) return false;
     unsigned b = 0;
-    if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
+    if (lane == 0) b = atomicAdd(K->batch_counter, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= P.total_batches) { q.exhausted = true; return false; }
-    const unsigned f = b / P.batches_per_frame;
-    const unsigned bi = b - f * P.batches_per_frame;
+    if (b >= K->total_batches) { q.exhausted = true; return false; }
+    const unsigned f = b / K->batches_per_frame;
+    const unsigned bi = b - f * K->batches_per_frame;
     q.frame = f;
-    q.pix = bi * P.batch;
-    const unsigned e = q.pix + P.batch;
-    q.end = e < P.npix_local ? e : P.npix_local;
+    q.pix = bi * K->batch;
+    const unsigned e = q.pix + K->batch;
+    q.end = e < K->npix_local ? e : K->npix_local;
     return true;
 }
 
@@ -1097,21 +1113,22 @@ PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
 // returns true when all 64 lanes started a primary ray
 PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
+    const pt_kargs_p K = pt_kargs();
     const unsigned avail = q.end - q.pix;
     const unsigned count = avail < 64u ? avail : 64u;
     if (lane < count) {
         const unsigned lp = q.pix + lane;
-        const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+        const unsigned lr = lp / (unsigned)K->width, x = lp - lr * (unsigned)K->width;
         unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
-        if (P.n_ranks > 1) {
-            const unsigned sl = lr / (unsigned)P.stripe_rows;
-            const unsigned within = lr - sl * (unsigned)P.stripe_rows;
-            grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+        if (K->n_ranks > 1) {
+            const unsigned sl = lr / (unsigned)K->stripe_rows;
+            const unsigned within = lr - sl * (unsigned)K->stripe_rows;
+            grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * (unsigned)K->stripe_rows + within;
         }
-        const unsigned gid = grow * (unsigned)P.width + x;
-        const int frame = P.frame_begin + (int)q.frame;
+        const unsigned gid = grow * (unsigned)K->width + x;
+        const int frame = K->frame_begin + (int)q.frame;
         s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-        pt_generate_ray((int)x, (int)grow, P.width, P.height, s.seed, s.o, s.d);      // :310
+        pt_generate_ray((int)x, (int)grow, K->width, K->height, s.seed, s.o, s.d);      // :310
         s.mask = mk3(1.0f, 1.0f, 1.0f);
         s.L = mk3(0.0f, 0.0f, 0.0f);
         s.bounce = 0;
@@ -1278,6 +1295,7 @@ void pt_trace_kernel(const PtTraceParams P)
 // dead lanes take the next samples of the wave's range, one by one (no coherence to keep here: the search dominates)
 PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
+    const pt_kargs_p K = pt_kargs();
     unsigned long long need = __ballot(!alive);
     while (need != 0ull && pt_queue_refill(P, lane, q)) {
         const unsigned n_need = (unsigned)__popcll(need);
@@ -1286,17 +1304,17 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
         const unsigned rank = pt_mbcnt(need);
         if (!alive && rank < take) {
             const unsigned lp = q.pix + rank;
-            const unsigned lr = lp / (unsigned)P.width, x = lp - lr * (unsigned)P.width;
+            const unsigned lr = lp / (unsigned)K->width, x = lp - lr * (unsigned)K->width;
             unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
-            if (P.n_ranks > 1) {
-                const unsigned sl = lr / (unsigned)P.stripe_rows;
-                const unsigned within = lr - sl * (unsigned)P.stripe_rows;
-                grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
+            if (K->n_ranks > 1) {
+                const unsigned sl = lr / (unsigned)K->stripe_rows;
+                const unsigned within = lr - sl * (unsigned)K->stripe_rows;
+                grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * (unsigned)K->stripe_rows + within;
             }
-            const unsigned gid = grow * (unsigned)P.width + x;
-            const int frame = P.frame_begin + (int)q.frame;
+            const unsigned gid = grow * (unsigned)K->width + x;
+            const int frame = K->frame_begin + (int)q.frame;
             s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-            pt_generate_ray((int)x, (int)grow, P.width, P.height, s.seed, s.o, s.d);      // :310
+            pt_generate_ray((int)x, (int)grow, K->width, K->height, s.seed, s.o, s.d);      // :310
             s.mask = mk3(1.0f, 1.0f, 1.0f);
             s.L = mk3(0.0f, 0.0f, 0.0f);
             s.bounce = 0;
