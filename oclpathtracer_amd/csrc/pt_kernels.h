@@ -78,6 +78,7 @@ struct PtTraceParams {
     unsigned int* batch_counter;  // zeroed before the launch
     unsigned long long* stats;    // may be null: [0] samples, [1] rays
     int32_t width, height;
+    float inv_width, inv_height, aspect;  // 1.0f / W, 1.0f / H, (float)W / (float)H (IEEE, host-computed: GenerateColors.cl:266-267)
     int32_t frame_begin;          // first frame of this chunk (global frame index)
     int32_t frame_count;          // frames in this chunk
     int32_t max_bounces, ntri, nmat;

@@ -155,22 +155,24 @@ __global__ void pt_prep_p1tab_kernel(const PtPrepTriangle* __restrict__ tris, in
 // ------------------------------------------------------------------------------------------
 // camera: GenerateColors.cl:73-87, 263-288
 // ------------------------------------------------------------------------------------------
-// the camera ray through image-plane position (x, y), in pixels (GenerateColors.cl:265-287 after the jitter)
-PTK_DEV void pt_camera_ray(float x, float y, int width, int height, f3& org, f3& dir_out)
+// the camera ray through image-plane position (x, y), in pixels (GenerateColors.cl:265-287 after the jitter).
+// inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H, aspect = (float)W / (float)H are IEEE quotients of image constants:
+// computed once on the host (PtTraceParams), the same bits as :266-267 evaluated per work-item.
+// The camera basis of :270-276 is a constant of the reference (eye, center = eye + (0,0,-1), up = (0,1,0)); evaluated
+// with PTSPEC's normalize / cross it is exactly
+//     viewDir = (+0, +0, -1)     holDir = normalize(cross(viewDir, up)) = (1, -0, +0)     upDir = normalize(cross(holDir, viewDir)) = (+0, 1, +0)
+// (every length is exactly 1; the signed zeros are those of the fma forms).  Using the constants keeps nine values out of
+// registers for the kernel's lifetime; the expression below is unchanged, so the results are too.
+PTK_DEV void pt_camera_ray(float x, float y, float inv_w, float inv_h, float aspect, f3& org, f3& dir_out)
 {
-    float invWidth = 1.0f / (float)width, invHeight = 1.0f / (float)height;
-    float aspectratio = (float)width / (float)height;
-    float angle = PTK_TAN_HALF_FOV;
-
+    const float angle = PTK_TAN_HALF_FOV;
     const f3 eye = mk3(PT_EYE_X, PT_EYE_Y, PT_EYE_Z);
-    const f3 center = add3(eye, mk3(0.0f, 0.0f, -1.0f));
-    const f3 up = mk3(0.0f, 1.0f, 0.0f);
-    const f3 viewDir = normalize3(sub3(center, eye));
-    const f3 holDir = normalize3(cross3(viewDir, up));
-    const f3 upDir = normalize3(cross3(holDir, viewDir));
+    const f3 viewDir = mk3(0.0f, 0.0f, -1.0f);
+    const f3 holDir = mk3(1.0f, -0.0f, 0.0f);
+    const f3 upDir = mk3(0.0f, 1.0f, 0.0f);
 
-    x = (2.0f * ((x + 0.5f) * invWidth) - 1.0f) * angle * aspectratio;
-    y = -(1.0f - 2.0f * ((y + 0.5f) * invHeight)) * angle;
+    x = (2.0f * ((x + 0.5f) * inv_w) - 1.0f) * angle * aspect;
+    y = -(1.0f - 2.0f * ((y + 0.5f) * inv_h)) * angle;
 
     float my = -1.0f * y;
     f3 d = add3(add3(scale3(holDir, x), scale3(upDir, my)), viewDir);
@@ -180,11 +182,11 @@ PTK_DEV void pt_camera_ray(float x, float y, int width, int height, f3& org, f3&
     dir_out = normalize3(normalize3(sub3(pointAimed, eye)));  // :287 then getRay's own normalize (:75)
 }
 
-PTK_DEV void pt_generate_ray(int xc, int yc, int width, int height, uint32_t& seed, f3& org, f3& dir_out)
+PTK_DEV void pt_generate_ray(int xc, int yc, float inv_w, float inv_h, float aspect, uint32_t& seed, f3& org, f3& dir_out)
 {
     float x = (float)xc + pt_random_float(seed) - 0.5f;  // :278-279: two draws, x first
     float y = (float)yc + pt_random_float(seed) - 0.5f;
-    pt_camera_ray(x, y, width, height, org, dir_out);
+    pt_camera_ray(x, y, inv_w, inv_h, aspect, org, dir_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,7 +228,7 @@ __global__ void pt_primary_mask_kernel(const PtMaskParams P)
         grow = (sl * (unsigned)P.n_ranks + (unsigned)P.rank) * (unsigned)P.stripe_rows + within;
     }
     f3 o, dc;
-    pt_camera_ray((float)x, (float)grow, P.width, P.height, o, dc);  // the jitter's midpoint: xi = 0.5
+    pt_camera_ray((float)x, (float)grow, 1.0f / (float)P.width, 1.0f / (float)P.height, (float)P.width / (float)P.height, o, dc);  // the jitter's midpoint: xi = 0.5
     const float hx = PTK_TAN_HALF_FOV * ((float)P.width / (float)P.height) / (float)P.width;
     const float hy = PTK_TAN_HALF_FOV / (float)P.height;
     const float eps = __builtin_sqrtf(hx * hx + hy * hy) * 1.01f + 4e-6f;
@@ -1036,6 +1038,8 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 
 struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, end) of local pixels of `frame`
     unsigned pix, end, frame;
+    unsigned row, col;       // local row / column of `pix`, kept incrementally: no per-lane division
+    unsigned sl, within;     // row = sl * stripe_rows + within (the stripe of the multi-GPU split)
     bool exhausted;
 };
 
@@ -1056,6 +1060,10 @@ PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue&
     q.pix = bi * K->batch;
     const unsigned e = q.pix + K->batch;
     q.end = e < K->npix_local ? e : K->npix_local;
+    q.row = q.pix / (unsigned)K->width;  // wave-uniform divisions, once per batch
+    q.col = q.pix - q.row * (unsigned)K->width;
+    q.sl = q.row / (unsigned)K->stripe_rows;
+    q.within = q.row - q.sl * (unsigned)K->stripe_rows;
     return true;
 }
 
@@ -1116,19 +1124,23 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
     const pt_kargs_p K = pt_kargs();
     const unsigned avail = q.end - q.pix;
     const unsigned count = avail < 64u ? avail : 64u;
+    const unsigned W = (unsigned)K->width, SR = (unsigned)K->stripe_rows;
     if (lane < count) {
         const unsigned lp = q.pix + lane;
-        const unsigned lr = lp / (unsigned)K->width, x = lp - lr * (unsigned)K->width;
-        unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
+        // local pixel -> (local row, column): walk from the range's own (row, col); 64 pixels span one or two rows
+        // unless the image is narrower than a wave
+        unsigned x = q.col + lane, up = 0u;
+        while (x >= W) { x -= W; ++up; }
+        unsigned grow = q.row + up;  // local row -> global row (image rows dealt to ranks in stripes)
         if (K->n_ranks > 1) {
-            const unsigned sl = lr / (unsigned)K->stripe_rows;
-            const unsigned within = lr - sl * (unsigned)K->stripe_rows;
-            grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * (unsigned)K->stripe_rows + within;
+            unsigned sl = q.sl, within = q.within + up;
+            while (within >= SR) { within -= SR; ++sl; }
+            grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * SR + within;
         }
-        const unsigned gid = grow * (unsigned)K->width + x;
+        const unsigned gid = grow * W + x;
         const int frame = K->frame_begin + (int)q.frame;
         s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-        pt_generate_ray((int)x, (int)grow, K->width, K->height, s.seed, s.o, s.d);      // :310
+        pt_generate_ray((int)x, (int)grow, K->inv_width, K->inv_height, K->aspect, s.seed, s.o, s.d);      // :310
         s.mask = mk3(1.0f, 1.0f, 1.0f);
         s.L = mk3(0.0f, 0.0f, 0.0f);
         s.bounce = 0;
@@ -1137,6 +1149,12 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
         alive = true;
     }
     q.pix += count;
+    q.col += count;
+    while (q.col >= W) {
+        q.col -= W;
+        ++q.row;
+        if (++q.within == SR) { q.within = 0u; ++q.sl; }
+    }
     return count == 64u;
 }
 
@@ -1169,7 +1187,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         tl.keys[lane] = ~0ull;
     }
 
-    PtWaveQueue q = { 0u, 0u, 0u, false };   // wave-uniform (SGPRs)
+    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, false };   // wave-uniform (SGPRs)
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
@@ -1314,7 +1332,7 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
             const unsigned gid = grow * (unsigned)K->width + x;
             const int frame = K->frame_begin + (int)q.frame;
             s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-            pt_generate_ray((int)x, (int)grow, K->width, K->height, s.seed, s.o, s.d);      // :310
+            pt_generate_ray((int)x, (int)grow, K->inv_width, K->inv_height, K->aspect, s.seed, s.o, s.d);      // :310
             s.mask = mk3(1.0f, 1.0f, 1.0f);
             s.L = mk3(0.0f, 0.0f, 0.0f);
             s.bounce = 0;
@@ -1359,7 +1377,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     }
     pt_const_f32p bigT = (pt_const_f32p)(const float*)P.bigtab;
 
-    PtWaveQueue q = { 0u, 0u, 0u, false };
+    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, false };
     bool alive = false;  // the lane holds a path
     bool trav = false;   // ... whose closest-hit search is in progress
     PtPath s;

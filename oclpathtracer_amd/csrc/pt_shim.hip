@@ -878,6 +878,9 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.stats = stats ? (unsigned long long*)stats->dptr : nullptr;
         tp.width = rp.width;
         tp.height = rp.height;
+        tp.inv_width = 1.0f / (float)rp.width;     // IEEE quotients: the translation unit is compiled without fast-math
+        tp.inv_height = 1.0f / (float)rp.height;
+        tp.aspect = (float)rp.width / (float)rp.height;
         tp.frame_begin = rp.frame_begin + f0;
         tp.frame_count = nf;
         tp.max_bounces = rp.max_bounces;
