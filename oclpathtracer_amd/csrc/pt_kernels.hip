@@ -440,6 +440,19 @@ struct PtTail {
     unsigned tile;     // TILED mode (pt_fetch_rec): dword offset of this wave's record tile in LDS
 };
 
+// a pending pair = triangle << 6 | ray lane: 2 bytes when the whole scene sits in the LDS table (<= 256 triangles: 14 bits),
+// 4 bytes otherwise
+typedef __attribute__((address_space(3))) unsigned short pt_lds_u16;
+template <int LDS_TABLE> PTK_DEV unsigned pt_tail_get(const PtTail& tl, unsigned i)
+{
+    return LDS_TABLE == 1 ? (unsigned)((pt_lds_u16*)tl.list)[i] : tl.list[i];
+}
+template <int LDS_TABLE> PTK_DEV void pt_tail_put(const PtTail& tl, unsigned i, unsigned pair)
+{
+    if (LDS_TABLE == 1) ((pt_lds_u16*)tl.list)[i] = (unsigned short)pair;
+    else tl.list[i] = pair;
+}
+
 // the reference's test of one (ray, triangle) pair without the running tmax: passes :100,:109,:117 and 0 < t < 1e20
 template <bool DET_BOUNDED>
 PTK_DEV bool pt_tri_candidate(const PtTriRec& r, const f3& o, const f3& d, float& t_out)
@@ -477,7 +490,7 @@ PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrep
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool act = lane < cnt;
-    const unsigned e = act ? tl.list[(tl.rd + lane) & (PT_TAIL_LIST - 1u)] : 0u;
+    const unsigned e = act ? pt_tail_get<LDS_TABLE>(tl, (tl.rd + lane) & (PT_TAIL_LIST - 1u)) : 0u;
     const unsigned ray = e & 63u, tri = e >> 6;
     const unsigned a = ray << 2;
     const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
@@ -520,7 +533,7 @@ PTK_DEV void pt_pass2_chunk(unsigned m, int base, int n, const PtPrepTriangle* t
                 asm("v_ffbh_u32_e32 %0, %1" : "=v"(lz) : "v"(m));
                 m &= ~(0x80000000u >> (lz & 31u));
                 const unsigned tri = (unsigned)(base + n - 32) + lz;
-                tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = (tri << 6) | lane;
+                pt_tail_put<LDS_TABLE>(tl, (tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u), (tri << 6) | lane);
             }
             tl.wr += (unsigned)__popcll(has);
             if (tl.wr - tl.rd >= 64u) {
@@ -1067,8 +1080,11 @@ PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue&
     return true;
 }
 
-// pool slot k of a wave: four float4 arrays of PT_POOL entries (conflict-free b128 accesses)
-//   [0] o.xyz d.x   [1] d.yz mask.xy   [2] mask.z L.xyz   [3] seed bounce lp fl
+// pool slot k of a wave: 60 bytes = three float4 arrays of PT_POOL entries (conflict-free b128 accesses) + one array of
+// three dwords.  (64-byte slots would put the workgroup over 160 KB / 8: the LDS is what decides whether 8 workgroups
+// -- 8 waves per SIMD -- fit a CU.)
+//   [0] o.xyz d.x   [1] d.yz mask.xy   [2] mask.z L.xyz   [3] seed, lp, fl | bounce << 16
+#define PT_POOL_DWORDS (PT_POOL * 15)
 PTK_DEV void pt_pool_push(float4* pool, unsigned& pool_n, const PtPath& s, bool& alive)
 {
     const unsigned long long live = __ballot(alive);
@@ -1077,8 +1093,10 @@ PTK_DEV void pt_pool_push(float4* pool, unsigned& pool_n, const PtPath& s, bool&
         pool[k] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
         pool[PT_POOL + k] = make_float4(s.d.y, s.d.z, s.mask.x, s.mask.y);
         pool[2 * PT_POOL + k] = make_float4(s.mask.z, s.L.x, s.L.y, s.L.z);
-        pool[3 * PT_POOL + k] = make_float4(__uint_as_float(s.seed), __int_as_float(s.bounce), __uint_as_float(s.lp),
-                                            __uint_as_float(s.fl));
+        unsigned* w = reinterpret_cast<unsigned*>(pool + 3 * PT_POOL) + 3u * k;
+        w[0] = s.seed;
+        w[1] = s.lp;
+        w[2] = s.fl | ((unsigned)s.bounce << 16);  // both below 65 536 (pt_render_frames checks)
     }
     pool_n += (unsigned)__popcll(live);
     alive = false;
@@ -1098,15 +1116,17 @@ PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
     const unsigned rank = pt_mbcnt(need);
     if (!alive && rank < take) {
         const unsigned k = pool_n - 1u - rank;
-        const float4 a0 = pool[k], a1 = pool[PT_POOL + k], a2 = pool[2 * PT_POOL + k], a3 = pool[3 * PT_POOL + k];
+        const float4 a0 = pool[k], a1 = pool[PT_POOL + k], a2 = pool[2 * PT_POOL + k];
+        const unsigned* w = reinterpret_cast<const unsigned*>(pool + 3 * PT_POOL) + 3u * k;
+        const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
         s.o = mk3(a0.x, a0.y, a0.z);
         s.d = mk3(a0.w, a1.x, a1.y);
         s.mask = mk3(a1.z, a1.w, a2.x);
         s.L = mk3(a2.y, a2.z, a2.w);
-        s.seed = __float_as_uint(a3.x);
-        s.bounce = __float_as_int(a3.y);
-        s.lp = __float_as_uint(a3.z);
-        s.fl = __float_as_uint(a3.w);
+        s.seed = w0;
+        s.lp = w1;
+        s.fl = w2 & 0xffffu;
+        s.bounce = (int)(w2 >> 16);
         alive = true;
     }
     pool_n -= take;
@@ -1173,17 +1193,18 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         __syncthreads();
     }
     // this wave's pool of parked paths, behind the triangle table (ptk_trace_lds_bytes)
-    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0)) + (threadIdx.x >> 6) * (4 * PT_POOL);
+    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + (threadIdx.x >> 6) * PT_POOL_DWORDS);
     unsigned pool_n = 0u;                    // parked paths (wave-uniform)
     // this wave's pass-2 tail: 64 key slots + the pending-pair ring, behind the four pools
     PtTail tl;
     {
-        const unsigned tails = (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + (PT_TRACE_THREADS / 64) * (16 * PT_POOL);
-        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + tails + (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
+        const unsigned tail_dw = 128u + (LDS_TABLE == 1 ? PT_TAIL_LIST / 2u : PT_TAIL_LIST);  // keys + pair ring (2-byte pairs beside the table)
+        const unsigned tails = (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + (PT_TRACE_THREADS / 64) * PT_POOL_DWORDS;
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + tails + (threadIdx.x >> 6) * tail_dw;
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
-        tl.tile = tails + (PT_TRACE_THREADS / 64) * (128u + PT_TAIL_LIST) + (threadIdx.x >> 6) * (32u * PT_LDS_TRI_STRIDE);  // (TILED mode only)
+        tl.tile = tails + (PT_TRACE_THREADS / 64) * tail_dw + (threadIdx.x >> 6) * (32u * PT_LDS_TRI_STRIDE);  // (TILED mode only)
         tl.keys[lane] = ~0ull;
     }
 
@@ -1270,18 +1291,28 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
-// 7 waves per SIMD: the kernel needs 67 VGPRs but 106 SGPRs, and SGPRs cap residency at 6 waves
-// (MI355X_MICROARCH.md: 256-thread blocks per CU = 800 / (ceil(sgpr/16)*16 + 16)); asking for 7
-// makes hipcc keep 94 SGPRs (a few spilled to VGPR lanes): 60.9 -> 59.8 ms when introduced; 8 waves
-// (64 VGPRs, 78 SGPRs, 10 + 28 spills) is slower again: 38.2 vs 36.8 ms.
+// Waves per SIMD.  More resident waves is what this issue-bound kernel wants (round 2, same source: 5 -> 35.8 ms,
+// 6 -> 34.1, 7 -> 32.0); three things had to give for 8: the arguments only regeneration and shading need are re-read
+// from the kernarg segment instead of living in SGPRs (pt_kargs: no v_readlane spills, 78 SGPRs), the fresh phase lost
+// its per-lane divisions and the camera basis its registers (64 VGPRs without scratch), and the LDS of a workgroup
+// shrank to 20 160 B (60-byte pool slots, 2-byte tail pairs) so that 8 workgroups fit the CU's 160 KB.
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 7
+#define PT_TRACE_WAVES 8
 #endif
 template <bool DET_BOUNDED, int LDS_TABLE, int QUADS>
 __global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
 void pt_trace_kernel(const PtTraceParams P)
 {
     pt_trace_body<DET_BOUNDED, LDS_TABLE, QUADS>(P);
+}
+
+// TILED brute force (257+ triangles): its LDS (pool + 4-byte pair ring + record tiles = 25.6 KB) admits 6 workgroups
+// per CU, so it may as well use the registers of 6 waves per SIMD
+template <bool DET_BOUNDED>
+__global__ __launch_bounds__(PT_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void pt_trace_tiled_kernel(const PtTraceParams P)
+{
+    pt_trace_body<DET_BOUNDED, 2, 0>(P);
 }
 
 // ---- the LBVH trace kernel -------------------------------------------------------------------------
@@ -1684,8 +1715,8 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
             hipLaunchKernelGGL((pt_trace_kernel<false, 1, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     } else {
         const size_t lds = ptk_trace_lds_bytes(p.ntri);
-        if (det_bounded) hipLaunchKernelGGL((pt_trace_kernel<true, 2, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((pt_trace_kernel<false, 2, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        if (det_bounded) hipLaunchKernelGGL(pt_trace_tiled_kernel<true>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+        else hipLaunchKernelGGL(pt_trace_tiled_kernel<false>, dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
     }
     return hipGetLastError();
 }
@@ -1731,10 +1762,11 @@ hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s)
 size_t ptk_trace_lds_bytes(int ntri)
 {
     const size_t table = ntri <= PT_LDS_TRI_MAX ? (size_t)ntri * PT_LDS_TRI_STRIDE * sizeof(float) : 0;
-    // per wave: the pool of parked paths (PT_POOL x 64 B) + the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
+    // per wave: the pool of parked paths (PT_POOL x 60 B) + the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 2 or 4 B pairs)
     // + for scenes too large for the table, the record tile of the current chunk (32 x 48 B)
     const size_t tile = ntri <= PT_LDS_TRI_MAX ? 0 : (size_t)32 * PT_LDS_TRI_STRIDE * sizeof(float);
-    return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL * 4 * sizeof(float4) + 64 * 8 + PT_TAIL_LIST * 4 + tile);
+    const size_t ring = ntri <= PT_LDS_TRI_MAX ? PT_TAIL_LIST * 2 : PT_TAIL_LIST * 4;
+    return table + (size_t)(PT_TRACE_THREADS / 64) * (PT_POOL_DWORDS * 4 + 64 * 8 + ring + tile);
 }
 
 size_t ptk_trace_bvh_lds_bytes(void)
@@ -1754,7 +1786,9 @@ int ptk_trace_bvh_blocks_per_cu(void)
 int ptk_trace_blocks_per_cu(int ntri)
 {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, 1, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
+    hipError_t e = ntri <= PT_LDS_TRI_MAX
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_kernel<true, 1, 3>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri))
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_tiled_kernel<true>, PT_TRACE_THREADS, ptk_trace_lds_bytes(ntri));
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

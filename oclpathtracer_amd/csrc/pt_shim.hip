@@ -785,6 +785,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         if (rp.reserved[i] != 0) return fail(PT_ERR_INVALID, "reserved fields must be zero");
     if ((long long)rp.width * rp.height > 0x7fffffffLL) return fail(PT_ERR_INVALID, "image too large");
     if ((long long)rp.frame_begin + rp.frame_count > 0x7fffffffLL) return fail(PT_ERR_INVALID, "frame index overflow");
+    if (rp.max_bounces > 65535) return fail(PT_ERR_INVALID, "max_bounces above 65535 (a parked path packs its bounce count in 16 bits)");
     int rows = pt_local_rows(rp.height, rp.stripe_rows, rp.n_ranks, rp.rank);
     uint64_t npix64 = (uint64_t)rows * (uint64_t)rp.width;
     if (pixel_count) {
@@ -823,6 +824,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         budget = std::max<uint64_t>(budget, d->rad_bytes);
     }
     int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 12)));
+    chunk = std::min(chunk, 65535);  // a parked path packs its frame-in-chunk in 16 bits
     if (d->opt_chunk > 0) chunk = (int)std::min<int64_t>(chunk, d->opt_chunk);
     int nchunks = (rp.frame_count + chunk - 1) / chunk;
     if (nchunks > PT_MAX_CHUNKS) {
