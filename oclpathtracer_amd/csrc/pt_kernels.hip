@@ -47,6 +47,9 @@ PTK_DEV pt_kargs_p pt_kargs()
     asm volatile("" : "+s"(k));
     return k;
 }
+// LATE (template parameter of the functions below): read the argument where it is used (the table trace kernels), or take
+// it from the by-value copy (the LBVH kernel, which has SGPRs to spare and measured 13 % slower with late reads)
+#define PT_ARG(field) (LATE ? K->field : P.field)
 
 // camera position, GenerateColors.cl:265
 #define PT_EYE_X 0.0f
@@ -427,7 +430,7 @@ PTK_DEV void pt_tri_pass2(const PtTriRec& r, int i, bool valid, const f3& o, con
 // same t, u, v bit for bit).  The list outlives the 32-triangle chunks of a large scene, so a brute-force
 // search over thousands of triangles runs its rare survivors at full lane width too.
 #ifndef PT_TAIL_LANES
-#define PT_TAIL_LANES 24  // own steps continue while more lanes than this still hold a survivor; 0 = never use the tail
+#define PT_TAIL_LANES 32  // own steps continue while more lanes than this still hold a survivor; 0 = never use the tail
 #endif
 #define PT_TAIL_LIST 128u  // list capacity: a round is run as soon as 64 pairs are pending, one append adds <= 64
 
@@ -883,7 +886,7 @@ struct PtPath {
 
 
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
-template <bool DET_BOUNDED>
+template <bool DET_BOUNDED, bool LATE>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
                       unsigned& n_rays, unsigned& n_samples, unsigned long long* sub = nullptr)
 {
@@ -916,15 +919,15 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
 
         // deferred HitRecord of the closest hit (:127-130): same values as writing it at every
         // acceptance, only the last one is read.
-        const float4 nid = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(K->tris + hidx) + 12);
+        const float4 nid = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(PT_ARG(tris) + hidx) + 12);
         const f3 N = mk3(nid.x, nid.y, nid.z);
         int mid = __float_as_int(nid.w);
-        mid = mid < 0 ? 0 : (mid >= K->nmat ? K->nmat - 1 : mid);  // never fault on a corrupt id
+        mid = mid < 0 ? 0 : (mid >= PT_ARG(nmat) ? PT_ARG(nmat) - 1 : mid);  // never fault on a corrupt id
         f3 p = add3(s.o, scale3(s.d, tmax));
         float w = 1.0f - hu - hv;
         f3 n = normalize3(add3(add3(scale3(N, hu), scale3(N, hv)), scale3(N, w)));
 
-        const PtRawMaterial* mat = K->mats + mid;  // :239
+        const PtRawMaterial* mat = PT_ARG(mats) + mid;  // :239
         const float4 alb = *reinterpret_cast<const float4*>(mat->albedo);
         const float4 emi = *reinterpret_cast<const float4*>(mat->emissive);
         const float rough = mat->roughness;
@@ -988,7 +991,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
             s.mask.y = s.mask.y * (color.y * dwin / pdf);
             s.mask.z = s.mask.z * (color.z * dwin / pdf);
             s.bounce++;
-            if (s.bounce >= K->max_bounces) {
+            if (s.bounce >= PT_ARG(max_bounces)) {
                 finished = true;
             } else {
                 s.o = add3(p, scale3(wi, 0.01f));  // :257
@@ -1002,7 +1005,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         // pmc_r02_summary.txt: 35.2 bytes of HBM traffic per sample against 41.0 with aligned 16-byte records --
         // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
         // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
-        float* out = K->rad + ((size_t)s.fl * K->npix_local + s.lp) * 3u;
+        float* out = PT_ARG(rad) + ((size_t)s.fl * PT_ARG(npix_local) + s.lp) * 3u;
         typedef float pt_f3v __attribute__((ext_vector_type(3)));
         pt_f3v v;
         v.x = pt_max(s.L.x, 0.0f);
@@ -1058,25 +1061,26 @@ struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, en
 
 // makes [q.pix, q.end) non-empty, taking the next batch off the global queue (one atomic per batch)
 // when the current one is used up; false when there is nothing left
+template <bool LATE>
 PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q)
 {
     const pt_kargs_p K = pt_kargs();
     if (q.pix != q.end) return true;
     if (q.exhausted) return false;
     unsigned b = 0;
-    if (lane == 0) b = atomicAdd(K->batch_counter, 1u);
+    if (lane == 0) b = atomicAdd(PT_ARG(batch_counter), 1u);
     b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= K->total_batches) { q.exhausted = true; return false; }
-    const unsigned f = b / K->batches_per_frame;
-    const unsigned bi = b - f * K->batches_per_frame;
+    if (b >= PT_ARG(total_batches)) { q.exhausted = true; return false; }
+    const unsigned f = b / PT_ARG(batches_per_frame);
+    const unsigned bi = b - f * PT_ARG(batches_per_frame);
     q.frame = f;
-    q.pix = bi * K->batch;
-    const unsigned e = q.pix + K->batch;
-    q.end = e < K->npix_local ? e : K->npix_local;
-    q.row = q.pix / (unsigned)K->width;  // wave-uniform divisions, once per batch
-    q.col = q.pix - q.row * (unsigned)K->width;
-    q.sl = q.row / (unsigned)K->stripe_rows;
-    q.within = q.row - q.sl * (unsigned)K->stripe_rows;
+    q.pix = bi * PT_ARG(batch);
+    const unsigned e = q.pix + PT_ARG(batch);
+    q.end = e < PT_ARG(npix_local) ? e : PT_ARG(npix_local);
+    q.row = q.pix / (unsigned)PT_ARG(width);  // wave-uniform divisions, once per batch
+    q.col = q.pix - q.row * (unsigned)PT_ARG(width);
+    q.sl = q.row / (unsigned)PT_ARG(stripe_rows);
+    q.within = q.row - q.sl * (unsigned)PT_ARG(stripe_rows);
     return true;
 }
 
@@ -1139,12 +1143,13 @@ PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
 // FRESH phase: every lane is dead (its path parked); the next (up to) 64 samples of the wave's range start
 // in lanes 0.. at bounce 0 -- seed :308, camera ray :310
 // returns true when all 64 lanes started a primary ray
+template <bool LATE>
 PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
     const pt_kargs_p K = pt_kargs();
     const unsigned avail = q.end - q.pix;
     const unsigned count = avail < 64u ? avail : 64u;
-    const unsigned W = (unsigned)K->width, SR = (unsigned)K->stripe_rows;
+    const unsigned W = (unsigned)PT_ARG(width), SR = (unsigned)PT_ARG(stripe_rows);
     if (lane < count) {
         const unsigned lp = q.pix + lane;
         // local pixel -> (local row, column): walk from the range's own (row, col); 64 pixels span one or two rows
@@ -1152,15 +1157,15 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
         unsigned x = q.col + lane, up = 0u;
         while (x >= W) { x -= W; ++up; }
         unsigned grow = q.row + up;  // local row -> global row (image rows dealt to ranks in stripes)
-        if (K->n_ranks > 1) {
+        if (PT_ARG(n_ranks) > 1) {
             unsigned sl = q.sl, within = q.within + up;
             while (within >= SR) { within -= SR; ++sl; }
-            grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * SR + within;
+            grow = (sl * (unsigned)PT_ARG(n_ranks) + (unsigned)PT_ARG(rank)) * SR + within;
         }
         const unsigned gid = grow * W + x;
-        const int frame = K->frame_begin + (int)q.frame;
+        const int frame = PT_ARG(frame_begin) + (int)q.frame;
         s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-        pt_generate_ray((int)x, (int)grow, K->inv_width, K->inv_height, K->aspect, s.seed, s.o, s.d);      // :310
+        pt_generate_ray((int)x, (int)grow, PT_ARG(inv_width), PT_ARG(inv_height), PT_ARG(aspect), s.seed, s.o, s.d);      // :310
         s.mask = mk3(1.0f, 1.0f, 1.0f);
         s.L = mk3(0.0f, 0.0f, 0.0f);
         s.bounce = 0;
@@ -1227,9 +1232,9 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         PT_STAMP(t0);
         bool primary = false;   // (wave-uniform) this bounce is a fresh wave of 64 primary rays
         if (__ballot(!alive) != 0ull) {
-            if (pool_n == 0u && pt_queue_refill(P, lane, q)) {
+            if (pool_n == 0u && pt_queue_refill<true>(P, lane, q)) {
                 pt_pool_push(pool, pool_n, s, alive);                // park every live path ...
-                primary = pt_start_fresh(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
+                primary = pt_start_fresh<true>(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
             }
             pt_pool_pop(pool, pool_n, s, alive);           // dead lanes resume parked paths
         }
@@ -1262,9 +1267,9 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 
         PT_STAMP(t2);
 #if PT_STAMPS == 2
-        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
+        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
 #else
-        if (alive) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
 #endif
 #if PT_STAMPS
         PT_STAMP(t3);
@@ -1336,34 +1341,37 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 // triangles tested (both per lane), traversal steps of the waves.  Never the timed kernel.
 #define PT_BVH_STACK 96        // a radix tree over 64-bit keys has at most 64 levels = 32 levels of four-child nodes,
                                // each of which stacks at most three children
+#ifndef PT_BVH_LDS_STACK
 #define PT_BVH_LDS_STACK 24
+#endif
 #ifndef PT_BVH_REFILL
 #define PT_BVH_REFILL 40
 #endif
 
 // dead lanes take the next samples of the wave's range, one by one (no coherence to keep here: the search dominates)
+template <bool LATE>
 PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, PtPath& s, bool& alive)
 {
     const pt_kargs_p K = pt_kargs();
     unsigned long long need = __ballot(!alive);
-    while (need != 0ull && pt_queue_refill(P, lane, q)) {
+    while (need != 0ull && pt_queue_refill<LATE>(P, lane, q)) {
         const unsigned n_need = (unsigned)__popcll(need);
         const unsigned avail = q.end - q.pix;
         const unsigned take = n_need < avail ? n_need : avail;
         const unsigned rank = pt_mbcnt(need);
         if (!alive && rank < take) {
             const unsigned lp = q.pix + rank;
-            const unsigned lr = lp / (unsigned)K->width, x = lp - lr * (unsigned)K->width;
+            const unsigned lr = lp / (unsigned)PT_ARG(width), x = lp - lr * (unsigned)PT_ARG(width);
             unsigned grow = lr;  // local row -> global row (image rows dealt to ranks in stripes)
-            if (K->n_ranks > 1) {
-                const unsigned sl = lr / (unsigned)K->stripe_rows;
-                const unsigned within = lr - sl * (unsigned)K->stripe_rows;
-                grow = (sl * (unsigned)K->n_ranks + (unsigned)K->rank) * (unsigned)K->stripe_rows + within;
+            if (PT_ARG(n_ranks) > 1) {
+                const unsigned sl = lr / (unsigned)PT_ARG(stripe_rows);
+                const unsigned within = lr - sl * (unsigned)PT_ARG(stripe_rows);
+                grow = (sl * (unsigned)PT_ARG(n_ranks) + (unsigned)PT_ARG(rank)) * (unsigned)PT_ARG(stripe_rows) + within;
             }
-            const unsigned gid = grow * (unsigned)K->width + x;
-            const int frame = K->frame_begin + (int)q.frame;
+            const unsigned gid = grow * (unsigned)PT_ARG(width) + x;
+            const int frame = PT_ARG(frame_begin) + (int)q.frame;
             s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
-            pt_generate_ray((int)x, (int)grow, K->inv_width, K->inv_height, K->aspect, s.seed, s.o, s.d);      // :310
+            pt_generate_ray((int)x, (int)grow, PT_ARG(inv_width), PT_ARG(inv_height), PT_ARG(aspect), s.seed, s.o, s.d);      // :310
             s.mask = mk3(1.0f, 1.0f, 1.0f);
             s.L = mk3(0.0f, 0.0f, 0.0f);
             s.bounce = 0;
@@ -1429,8 +1437,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 
     for (;;) {
         if ((unsigned)__popcll(__ballot(trav)) <= (unsigned)PT_BVH_REFILL) {
-            if (alive && !trav) pt_shade<DET_BOUNDED>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
-            pt_regenerate_lanes(P, lane, q, s, alive);
+            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+            pt_regenerate_lanes<false>(P, lane, q, s, alive);
             const bool start = alive && !trav;
             if (__ballot(start) != 0ull) {
                 if (start) { tmax = 1e20f; hu = 0.0f; hv = 0.0f; hidx = -1; }
