@@ -1551,8 +1551,13 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
+#ifdef PT_BVH_WAVES
+#define PT_BVH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PT_BVH_WAVES, PT_BVH_WAVES)))
+#else
+#define PT_BVH_WAVES_ATTR
+#endif
 template <bool DET_BOUNDED, bool TALLY>
-__global__ __launch_bounds__(PT_TRACE_THREADS)
+__global__ __launch_bounds__(PT_TRACE_THREADS) PT_BVH_WAVES_ATTR
 void pt_trace_bvh_kernel(const PtTraceParams P)
 {
     pt_trace_bvh_body<DET_BOUNDED, TALLY>(P);
