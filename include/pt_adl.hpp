@@ -189,7 +189,7 @@ struct Buffer : public BufferBase {
         }
         m_handle = b;
         m_size = nElems;
-        m_ptr = (T*)pt_buffer_device_ptr(b);
+        m_ptr = (T*)pt_buffer_address(b);  // the address as a value (the reference's m_ptr is the opaque cl_mem); getInternalObject() licenses access
     }
     // Buffer<T>::setRawPtr: adopt caller-owned device memory (Adl/Adl.h:214)
     void setRawPtr(const Device* device, T* ptr, adlu64 size, BufferType = BUFFER)
@@ -237,7 +237,8 @@ struct Buffer : public BufferBase {
         m_mapped = 0;
     }
     adlu64 getSize() const { return m_size; }
-    void* getInternalObject() { return m_ptr; }
+    // the device pointer for code that touches the memory itself: submits deferred frames and ends frame batching for this buffer
+    void* getInternalObject() { return m_handle ? pt_buffer_device_ptr(m_handle) : (void*)m_ptr; }
     DeviceType getType() const { return m_device->m_type; }
 
     void release()

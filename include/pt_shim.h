@@ -148,6 +148,10 @@ size_t pt_buffer_size(pt_buffer_t buf);
 /* Buffer<T>::getInternalObject / m_ptr.  Submits deferred frames that touch the buffer and
  * switches frame batching off for it from now on (the caller can see the memory directly). */
 void* pt_buffer_device_ptr(pt_buffer_t buf);
+/* The buffer's device address as a VALUE (the facade's public Buffer<T>::m_ptr member, which in the reference holds
+ * the opaque cl_mem: printing, identity).  It does not license access to the memory behind this ABI and changes
+ * nothing; code that wants to read or write the memory itself must obtain the pointer with pt_buffer_device_ptr. */
+void* pt_buffer_address(pt_buffer_t buf);
 /* Buffer<T>::write / read (host) -> clEnqueueWrite/ReadBuffer : AdlCL.inl:297-340.
  * Asynchronous w.r.t. the host like the reference (non-blocking enqueue); the host range
  * must stay valid until pt_sync / the event.  ev may be NULL. */

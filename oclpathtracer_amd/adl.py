@@ -255,6 +255,13 @@ class Buffer:
 
     @property
     def m_ptr(self) -> int:
+        """The device address as a value (the reference's m_ptr holds the opaque cl_mem).  It does not license
+        access to the memory behind the API: take the pointer from getInternalObject() for that."""
+        return (self.m_device._lib.pt_buffer_address(self._h) or 0) if self._h else 0
+
+    def getInternalObject(self) -> int:
+        """Buffer<T>::getInternalObject: the device pointer for code that touches the memory itself (a torch
+        tensor view, another library).  Submits deferred frames and ends frame batching for this buffer."""
         return (self.m_device._lib.pt_buffer_device_ptr(self._h) or 0) if self._h else 0
 
     def getSize(self) -> int:

@@ -457,6 +457,8 @@ extern "C" int pt_buffer_free(pt_buffer_t b)
 }
 
 extern "C" size_t pt_buffer_size(pt_buffer_t b) { return b ? b->bytes : 0; }
+extern "C" void* pt_buffer_address(pt_buffer_t b) { return b ? b->dptr : nullptr; }
+
 extern "C" void* pt_buffer_device_ptr(pt_buffer_t b)
 {
     if (!b) return nullptr;

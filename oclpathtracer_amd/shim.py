@@ -79,6 +79,7 @@ SIGNATURES = {
     "pt_buffer_free": (_c.c_int, [_H]),
     "pt_buffer_size": (_c.c_size_t, [_H]),
     "pt_buffer_device_ptr": (_c.c_void_p, [_H]),
+    "pt_buffer_address": (_c.c_void_p, [_H]),
     "pt_buffer_write": (_c.c_int, [_H, _c.c_void_p, _c.c_size_t, _c.c_size_t, _H]),
     "pt_buffer_read": (_c.c_int, [_H, _c.c_void_p, _c.c_size_t, _c.c_size_t, _H]),
     "pt_buffer_copy": (_c.c_int, [_H, _H, _c.c_size_t, _c.c_size_t, _c.c_size_t, _H]),

@@ -135,7 +135,9 @@ def test_wrapped_buffers_are_never_deferred(device, cornell):
     fb2 = adl.Buffer(device, dim * dim, adl.float4)
     launch(tb, mb, fb2, 0)
     launch(tb, mb, fb2, 1)
-    ptr = fb2.m_ptr                       # pt_buffer_device_ptr: flushes, switches batching off for fb2
+    assert fb2.m_ptr != 0                 # the address as a value: changes nothing
+    ptr = fb2.getInternalObject()         # pt_buffer_device_ptr: flushes, switches batching off for fb2
+    assert ptr == fb2.m_ptr
     device.waitForCompletion()
     raw = np.empty((dim * dim, 4), np.float32)
     assert lib.pt_buffer_read(fb2._h, raw.ctypes.data_as(ctypes.c_void_p), raw.nbytes, 0, None) == 0
