@@ -441,6 +441,9 @@ struct PtTail {
     pt_lds_u32* list;  // [PT_TAIL_LIST]  pending pairs: triangle << 6 | ray lane  (ring)
     unsigned wr, rd;   // wave-uniform ring positions
     unsigned tile;     // TILED mode (pt_fetch_rec): dword offset of this wave's record tile in LDS
+    // per lane (as the owner of a ray): the best key its slot has held so far and the (u, v) that came with it
+    unsigned long long kbest;
+    float ku, kv;
 };
 
 // a pending pair = triangle << 6 | ray lane: 2 bytes when the whole scene sits in the LDS table (<= 256 triangles: 14 bits),
@@ -458,7 +461,7 @@ template <int LDS_TABLE> PTK_DEV void pt_tail_put(const PtTail& tl, unsigned i, 
 
 // the reference's test of one (ray, triangle) pair without the running tmax: passes :100,:109,:117 and 0 < t < 1e20
 template <bool DET_BOUNDED>
-PTK_DEV bool pt_tri_candidate(const PtTriRec& r, const f3& o, const f3& d, float& t_out)
+PTK_DEV bool pt_tri_candidate(const PtTriRec& r, const f3& o, const f3& d, float& t_out, float& u_out, float& v_out)
 {
     float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
     float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
@@ -476,6 +479,8 @@ PTK_DEV bool pt_tri_candidate(const PtTriRec& r, const f3& o, const f3& d, float
     float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
     ok &= (tt > 0.0f) & (tt < 1e20f);  // :125 against the initial tmax (:141)
     t_out = tt;
+    u_out = u;
+    v_out = v;
     return ok;
 }
 
@@ -499,12 +504,25 @@ PTK_DEV void pt_tail_round(PtTail& tl, unsigned cnt, unsigned lane, const PtPrep
     const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
     const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
     const PtTriRec r = pt_fetch_rec<(LDS_TABLE == 1 ? 1 : 0)>(tris, (int)tri);  // (a pending pair may be of an earlier chunk than the tile's)
-    float t;
-    const bool ok = pt_tri_candidate<DET_BOUNDED>(r, po, pd, t) & act;
+    float t, u, v;
+    const bool ok = pt_tri_candidate<DET_BOUNDED>(r, po, pd, t, u, v) & act;
     if (ok) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri;
+        // key = t bits | triangle | the lane that tested the pair: the minimum is the reference's winner (t, then the
+        // lower index; a ray's pairs have distinct triangles), and its low bits say where its (u, v) are
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((tri << 6) | lane);
         __hip_atomic_fetch_min(tl.keys + ray, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
+    // every lane, now as the owner of its ray: did this round improve my slot?  Then fetch (u, v) from the lane that did it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long slot = tl.keys[lane];
+    const unsigned from = ((unsigned)slot & 63u) << 2;
+    const float pu = pt_from_lane(from, u), pv = pt_from_lane(from, v);
+    const bool changed = slot != tl.kbest;
+    tl.kbest = slot;
+    tl.ku = changed ? pu : tl.ku;
+    tl.kv = changed ? pv : tl.kv;
     tl.rd += cnt;
 }
 
@@ -561,20 +579,16 @@ PTK_DEV void pt_pass2_finish(const PtPrepTriangle* tris, const f3& o, const f3& 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const unsigned long long key = tl.keys[lane];
             tl.keys[lane] = ~0ull;
+            const unsigned long long key = tl.kbest;
             const float kt = __uint_as_float((unsigned)(key >> 32));
-            const int ki = (int)(unsigned)key;
+            const int ki = (int)((unsigned)key >> 6);
             // the reference's winner is the lexicographic minimum of (t, index)
             const bool better = (key != ~0ull) & ((kt < tmax) | ((kt == tmax) & (ki < hidx)));
-            if (PT_LANES(better) != 0ull) {
-                ++steps;
-                const int i = (LDS_TABLE == 1 || better) ? ki : 0;
-                const PtTriRec r = pt_fetch_rec<(LDS_TABLE == 1 ? 1 : 0)>(tris, i);
-                float tm = better ? 1e20f : tmax;  // (a lane that is not `better` must keep its own result: valid = false)
-                pt_tri_pass2<DET_BOUNDED>(r, i, better, o, d, tm, hu, hv, hidx);
-                tmax = tm;
-            }
+            tmax = better ? kt : tmax;
+            hu = better ? tl.ku : hu;
+            hv = better ? tl.kv : hv;
+            hidx = better ? ki : hidx;
         }
     }
 }
@@ -676,6 +690,7 @@ PTK_DEV unsigned pt_intersect_two_pass(pt_const_f32p T, const PtPrepTriangle* tr
                                        unsigned long long* vstat = nullptr, unsigned long long* p1_ticks = nullptr)
 {
     tl.wr = tl.rd = 0u;
+    tl.kbest = ~0ull;
 #if PT_STAMPS
     unsigned long long ta = 0, tb = 0;
 #endif
@@ -794,6 +809,7 @@ PTK_DEV unsigned pt_intersect_primary(pt_const_f32p T, const PtPrepTriangle* tri
 {
     (void)T; (void)vstat;
     tl.wr = tl.rd = 0u;
+    tl.kbest = ~0ull;
     unsigned steps = 0;
     for (int base = 0; base < ntri; base += 32) {
         const int n = ntri - base < 32 ? ntri - base : 32;
@@ -1209,6 +1225,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
+        tl.kbest = ~0ull; tl.ku = tl.kv = 0.0f;
         tl.tile = tails + (PT_TRACE_THREADS / 64) * tail_dw + (threadIdx.x >> 6) * (32u * PT_LDS_TRI_STRIDE);  // (TILED mode only)
         tl.keys[lane] = ~0ull;
     }
@@ -1411,6 +1428,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
         tl.wr = tl.rd = 0u;
+        tl.kbest = ~0ull; tl.ku = tl.kv = 0.0f;
         tl.tile = 0u;
         tl.keys[lane] = ~0ull;
     }

@@ -813,6 +813,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     const bool use_bvh = rp.num_triangles >= 2 &&
                          (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
     if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
+    if (!use_bvh && rp.num_triangles >= (1 << 26))
+        return fail(PT_ERR_INVALID, "the brute-force search packs a triangle index in 26 bits: use PT_OPT_ACCEL 0 or 2 for %d triangles", rp.num_triangles);
 
     // frames per chunk: radiance staging is 12 B x pixels x frames
     // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
