@@ -249,50 +249,69 @@ __global__ void pt_bvh_leaf_tris_kernel(const unsigned long long* __restrict__ k
 
 __device__ __forceinline__ float pt_bvh_decode(unsigned q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
 
-// binary fp32 nodes -> the 64-byte four-child nodes the traversal reads (PtBvhNode4).  One thread per binary node;
-// nodes at odd depth are absorbed into their parents and write nothing.
-__global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n, PtBvhNode4* __restrict__ out)
+// binary fp32 nodes -> the one-line PT_BVH_WIDTH-child nodes the traversal reads (PtBvhWideNode).  One thread per binary
+// node; nodes whose depth is not a multiple of PT_BVH_LEVELS are absorbed into an ancestor and write nothing.
+__global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n, PtBvhWideNode* __restrict__ out)
 {
+    constexpr int W = PT_BVH_WIDTH;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     int depth = 0;
     for (int p = parent[i]; p >= 0 && depth < 256; p = parent[p]) ++depth;
-    if (depth & 1) return;
-    // the (up to four) children: a child of the binary node that is a leaf stays; an internal child is replaced by its two
-    unsigned link[4] = { PT_BVH_ABSENT, PT_BVH_ABSENT, PT_BVH_ABSENT, PT_BVH_ABSENT };
-    float lo[4][3], hi[4][3];
+    if (depth % PT_BVH_LEVELS) return;
+    // the (up to W) children: the binary node's two, then PT_BVH_LEVELS - 1 times every internal one replaced by its
+    // two (a leaf stays); in-order, so the children stay in Morton order
+    unsigned link[W];
+    float lo[W][3], hi[W][3];
     int m = 0;
-    const PtBvhNode w = wide[i];
-    for (int c = 0; c < 2; ++c) {
-        const unsigned l = c ? w.link_r : w.link_l;
-        const float* blo = c ? w.rmin : w.lmin;
-        const float* bhi = c ? w.rmax : w.lmax;
-        if (l & 0x80000000u) {
-            link[m] = l;
-            for (int a = 0; a < 3; ++a) { lo[m][a] = blo[a]; hi[m][a] = bhi[a]; }
-            ++m;
-        } else {
-            const PtBvhNode g = wide[l];
-            link[m] = g.link_l;
-            for (int a = 0; a < 3; ++a) { lo[m][a] = g.lmin[a]; hi[m][a] = g.lmax[a]; }
-            ++m;
-            link[m] = g.link_r;
-            for (int a = 0; a < 3; ++a) { lo[m][a] = g.rmin[a]; hi[m][a] = g.rmax[a]; }
-            ++m;
+    {
+        const PtBvhNode w = wide[i];
+        link[0] = w.link_l; link[1] = w.link_r;
+        for (int a = 0; a < 3; ++a) { lo[0][a] = w.lmin[a]; hi[0][a] = w.lmax[a]; lo[1][a] = w.rmin[a]; hi[1][a] = w.rmax[a]; }
+        m = 2;
+    }
+    for (int round = 1; round < PT_BVH_LEVELS; ++round) {
+        unsigned l2[W];
+        float lo2[W][3], hi2[W][3];
+        int m2 = 0;
+        for (int k = 0; k < m; ++k) {
+            if (link[k] & 0x80000000u) {
+                l2[m2] = link[k];
+                for (int a = 0; a < 3; ++a) { lo2[m2][a] = lo[k][a]; hi2[m2][a] = hi[k][a]; }
+                ++m2;
+            } else {
+                const PtBvhNode g = wide[link[k]];
+                l2[m2] = g.link_l;
+                for (int a = 0; a < 3; ++a) { lo2[m2][a] = g.lmin[a]; hi2[m2][a] = g.lmax[a]; }
+                ++m2;
+                l2[m2] = g.link_r;
+                for (int a = 0; a < 3; ++a) { lo2[m2][a] = g.rmin[a]; hi2[m2][a] = g.rmax[a]; }
+                ++m2;
+            }
+        }
+        m = m2;
+        for (int k = 0; k < m; ++k) {
+            link[k] = l2[k];
+            for (int a = 0; a < 3; ++a) { lo[k][a] = lo2[k][a]; hi[k][a] = hi2[k][a]; }
         }
     }
-    bool present[4] = { false, false, false, false };
+    for (int k = m; k < W; ++k) {
+        link[k] = PT_BVH_ABSENT;
+        for (int a = 0; a < 3; ++a) { lo[k][a] = 3.0e38f; hi[k][a] = -3.0e38f; }
+    }
+    bool present[W];
+    for (int k = 0; k < W; ++k) present[k] = false;
     for (int k = 0; k < m; ++k) {
         bool ok = true;
         for (int a = 0; a < 3; ++a) ok = ok && (lo[k][a] <= hi[k][a]);  // empty (3e38, -3e38) or NaN boxes are absent
         present[k] = ok;
         if (!ok) link[k] = PT_BVH_ABSENT;
     }
-    PtBvhNode4 o;
+    PtBvhWideNode o;
     unsigned ex[3] = { 1u, 1u, 1u };
     for (int a = 0; a < 3; ++a) {
         float org = 3.0e38f, top = -3.0e38f;
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < W; ++k)
             if (present[k]) { org = fminf(org, lo[k][a]); top = fmaxf(top, hi[k][a]); }
         if (!(org <= top)) { org = 0.0f; top = 0.0f; }
         o.origin[a] = org;
@@ -306,7 +325,7 @@ __global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const
         for (;;) {
             const float step = __uint_as_float((unsigned)be << 23);
             bool ok = true;
-            for (int k = 0; k < 4 && ok; ++k) {
+            for (int k = 0; k < W && ok; ++k) {
                 unsigned ql = 255u, qh = 0u;  // an absent child: inverted (and its link says so)
                 if (present[k]) {
                     float fl = floorf((lo[k][a] - org) / step), fh = ceilf((hi[k][a] - org) / step);
@@ -326,8 +345,8 @@ __global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const
         ex[a] = (unsigned)be;
     }
     o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-    for (int k = 0; k < 4; ++k) o.link[k] = link[k];
-    o.pad[0] = o.pad[1] = 0u;
+    for (int k = 0; k < W; ++k) o.link[k] = link[k];
+    for (unsigned k = 0; k < sizeof o.pad / sizeof o.pad[0]; ++k) o.pad[k] = 0u;
     out[i] = o;
 }
 
@@ -345,7 +364,7 @@ size_t ptk_bvh_temp_bytes(int ntri)
     return 16 * n + 8 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024 + sizeof(PtBvhNode) * n + 512;  // + leaf keys, the fp32 nodes
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode4* nodes4, PtLeafTri* ltris,
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhWideNode* nodes4, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only

@@ -34,24 +34,35 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
-// The node the trace kernel walks: 64 bytes = one L2-miss transaction, FOUR children.  The search is bound by
-// the bytes its L2 misses pull in (profiles/r02/pmc_soup_lbvh_32B_nodes.txt: 46 % L2 hit rate, 3.9 TB/s of
-// 64-byte fetches of which a two-child 32-byte node used half), so a node is exactly one such fetch and all
-// of it is used: the binary radix tree is collapsed two levels at a time (every binary node at even depth
-// becomes a node whose children are its grandchildren, or a child that is a leaf), nodes keep their binary
-// indices (the odd levels' slots stay empty).  The children's boxes are quantised to 8 bits per coordinate in
-// the node's own frame (origin = lower corner of their union, one power-of-two step per axis), rounded
-// OUTWARD and verified at build time with the very expression the traversal decodes them with
-// (fma(q, step, origin)): the decoded box contains the fp32 box.
-struct PtBvhNode4 {
+// The node the trace kernel walks: ONE cache line, PT_BVH_WIDTH children.  The search is bound by the line requests
+// its L2 misses make (profiles/r02/pmc_soup_lbvh_32B_nodes.txt: 46 % L2 hit rate, 3.9 TB/s of 64-byte fetches of which
+// a two-child 32-byte node used half; tools/ubench_gather: dependent random reads of a 70 MB table run at 75 G/s for
+// 64-byte records and at 86 G/s for aligned 128-byte records), so a node is exactly one such line and all of it is
+// used: the binary radix tree is collapsed PT_BVH_LEVELS levels at a time (every binary node at a depth that is a
+// multiple of PT_BVH_LEVELS becomes a node whose children are its descendants PT_BVH_LEVELS further down, or shallower
+// ones that are leaves), nodes keep their binary indices (the other levels' slots stay empty).  The children's boxes
+// are quantised to 8 bits per coordinate in the node's own frame (origin = lower corner of their union, one
+// power-of-two step per axis), rounded OUTWARD and verified at build time with the very expression the traversal
+// decodes them with (fma(q, step, origin)): the decoded box contains the fp32 box.
+#ifndef PT_BVH_WIDTH
+#define PT_BVH_WIDTH 4
+#endif
+#if PT_BVH_WIDTH == 4
+#define PT_BVH_LEVELS 2
+#elif PT_BVH_WIDTH == 8
+#define PT_BVH_LEVELS 3
+#else
+#error "PT_BVH_WIDTH is 4 (64-byte nodes) or 8 (128-byte nodes)"
+#endif
+struct alignas(16 * PT_BVH_WIDTH) PtBvhWideNode {
     float origin[3];
-    uint32_t meta;      // step exponents (biased as in binary32) x | y << 8 | z << 16
-    uint32_t link[4];   // child k: node index, 0x80000000 | leaf, or PT_BVH_ABSENT
-    uint8_t q[24];      // child k: min xyz at q[6k], max xyz at q[6k + 3]
-    uint32_t pad[2];
+    uint32_t meta;                  // step exponents (biased as in binary32) x | y << 8 | z << 16
+    uint32_t link[PT_BVH_WIDTH];    // child k: node index, 0x80000000 | leaf, or PT_BVH_ABSENT
+    uint8_t q[6 * PT_BVH_WIDTH];    // child k: min xyz at q[6k], max xyz at q[6k + 3]
+    uint32_t pad[(6 * PT_BVH_WIDTH - 16) / 4];
 };
-static_assert(sizeof(PtBvhNode4) == 64, "bvh node layout");
-#define PT_BVH_ABSENT 0xffffffffu  // nothing to visit in this slot (fewer than four children; non-finite triangles;
+static_assert(sizeof(PtBvhWideNode) == 16 * PT_BVH_WIDTH, "bvh node layout");
+#define PT_BVH_ABSENT 0xffffffffu  // nothing to visit in this slot (fewer children than slots; non-finite triangles;
                                    // triangles kept out of the hierarchy)
 
 // A LEAF of the hierarchy is a run of 1 << PT_BVH_CLUSTER_SHIFT consecutive triangles of the Morton order, walked
@@ -90,7 +101,7 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvhNode4* bvh;        // accel = BVH: four-child nodes at the binary tree's even-depth indices, root 0
+    const PtBvhWideNode* bvh;        // accel = BVH: four-child nodes at the binary tree's even-depth indices, root 0
     const PtLeafTri* ltris;       // accel = BVH: the triangles in Morton-sorted order; leaf c holds [c << shift, (c + 1) << shift)
     int32_t bvh_shift;            //              log2(triangles per leaf): PT_BVH_CLUSTER_SHIFT, or 0 for tiny scenes
     int32_t bvh_leaves;           //              number of leaves; the hierarchy has bvh_leaves - 1 nodes, root 0
@@ -135,7 +146,7 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
 // nodes[ptk_bvh_leaf_count(ntri) - 1] and ltris[ntri] (device memory) receive the hierarchy the trace kernel walks
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhNode4* nodes, PtLeafTri* ltris,
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhWideNode* nodes, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
 static inline int ptk_bvh_shift(int ntri) { return ntri >= 4 * PT_BVH_CLUSTER ? PT_BVH_CLUSTER_SHIFT : 0; }
 static inline int ptk_bvh_leaf_count(int ntri) { const int sh = ptk_bvh_shift(ntri); return (ntri + (1 << sh) - 1) >> sh; }

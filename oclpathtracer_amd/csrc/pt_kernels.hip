@@ -1348,16 +1348,17 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 //   * per-lane stack: PT_BVH_LDS_STACK entries in LDS (entry-major: conflict-free), deeper ones in a private array;
 //   * the triangles the builder kept out of the hierarchy (pt_bvh.hip: the few that span the scene) are searched
 //     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
-//   * the search is bound by the bytes its L2 misses fetch, so a node is one 64-byte line holding FOUR children
-//     (PtBvhNode4: the binary radix tree collapsed two levels at a time, 8-bit boxes in the node's own frame,
-//     conservative by construction), visited nearest first; a leaf is a 48-byte record of the Morton-sorted copy
+//   * the search is bound by the line requests its L2 misses make, so a node is one line holding PT_BVH_WIDTH children
+//     (PtBvhWideNode: the binary radix tree collapsed PT_BVH_LEVELS levels at a time, 8-bit boxes in the node's own
+//     frame, conservative by construction), visited nearest first; a leaf is a 48-byte record of the Morton-sorted copy
 //     of the triangles;
 //   * every link is visited at most once; a step budget and index checks make a damaged hierarchy end the
 //     search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
 // triangles tested (both per lane), traversal steps of the waves.  Never the timed kernel.
-#define PT_BVH_STACK 96        // a radix tree over 64-bit keys has at most 64 levels = 32 levels of four-child nodes,
-                               // each of which stacks at most three children
+// a radix tree over 64-bit keys has at most 64 levels = 32 levels of four-child nodes, each of which stacks at most
+// three children (22 levels of eight-child nodes: seven each)
+#define PT_BVH_STACK (PT_BVH_WIDTH == 4 ? 96 : 160)
 #ifndef PT_BVH_LDS_STACK
 #define PT_BVH_LDS_STACK 24
 #endif
@@ -1502,20 +1503,31 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if ((idx & tmask) != tmask && idx + 1u < (unsigned)ntri) { next = cur + 1u; pop = false; }
             } else {
                 if (TALLY) ++c_nodes;
+                constexpr int W = PT_BVH_WIDTH;
                 const uint4* np = reinterpret_cast<const uint4*>(P.bvh + idx);
-                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-                const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-                const unsigned meta = w0.w;
+                uint4 nw[1 + W / 4 + (6 * W + 15) / 16];  // origin + meta | links | boxes (the padding is not fetched)
+#pragma unroll
+                for (int k = 0; k < 1 + W / 4 + (6 * W + 15) / 16; ++k) nw[k] = np[k];
+                const float ox = __uint_as_float(nw[0].x), oy = __uint_as_float(nw[0].y), oz = __uint_as_float(nw[0].z);
+                const unsigned meta = nw[0].w;
                 const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
                             sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-                // the four children: boxes decoded exactly as pt_bvh_collapse_kernel verified (fma(q, step, origin)),
+                // the children: boxes decoded exactly as pt_bvh_collapse_kernel verified (fma(q, step, origin)),
                 // entry distance +Inf for a child that is absent or missed
-                const unsigned qw[6] = { w2.x, w2.y, w2.z, w2.w, w3.x, w3.y };  // 24 bytes: child k at bytes 6k .. 6k+5
-                unsigned lk[4] = { w1.x, w1.y, w1.z, w1.w };
-                float tk[4];
+                unsigned qw[(6 * W + 3) / 4];  // 6 W bytes: child k at bytes 6k .. 6k+5
+                unsigned lk[W];
+                float tk[W];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // byte j of the 24 (little endian): (qw[j >> 2] >> (8 * (j & 3))) & 255
+                for (int k = 0; k < W / 4; ++k) { lk[4 * k] = nw[1 + k].x; lk[4 * k + 1] = nw[1 + k].y; lk[4 * k + 2] = nw[1 + k].z; lk[4 * k + 3] = nw[1 + k].w; }
+#pragma unroll
+                for (int k = 0; k < (6 * W + 15) / 16; ++k) {
+                    const uint4 v = nw[1 + W / 4 + k];
+                    qw[4 * k] = v.x; qw[4 * k + 1] = v.y;
+                    if (4 * k + 2 < (6 * W + 3) / 4) { qw[4 * k + 2] = v.z; qw[4 * k + 3] = v.w; }
+                }
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    // byte j of the 6 W (little endian): (qw[j >> 2] >> (8 * (j & 3))) & 255
                     float4 bmin, bmax;
                     bmin.x = pt_fma((float)((qw[(6 * k + 0) >> 2] >> (8 * ((6 * k + 0) & 3))) & 255u), sx, ox);
                     bmin.y = pt_fma((float)((qw[(6 * k + 1) >> 2] >> (8 * ((6 * k + 1) & 3))) & 255u), sy, oy);
@@ -1528,14 +1540,24 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     const bool hit = pt_slab(bmin, bmax, s.o, ix, iy, iz, tmax, tn) & (lk[k] != PT_BVH_ABSENT);
                     tk[k] = hit ? tn : __builtin_inff();
                 }
-                // nearest first: sort the four (distance, link) pairs (5 compare-exchanges; misses sink to the end) ...
+                // nearest first: sort the (distance, link) pairs (a 5- or 19-exchange network; misses sink to the end) ...
 #define PT_CE(a, b) { const bool sw = tk[b] < tk[a]; const float ta_ = sw ? tk[b] : tk[a], tb_ = sw ? tk[a] : tk[b]; \
                       const unsigned la_ = sw ? lk[b] : lk[a], lb_ = sw ? lk[a] : lk[b]; tk[a] = ta_; tk[b] = tb_; lk[a] = la_; lk[b] = lb_; }
+#if PT_BVH_WIDTH == 4
                 PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#else
+                PT_CE(0, 1) PT_CE(2, 3) PT_CE(4, 5) PT_CE(6, 7)
+                PT_CE(0, 2) PT_CE(1, 3) PT_CE(4, 6) PT_CE(5, 7)
+                PT_CE(1, 2) PT_CE(5, 6) PT_CE(0, 4) PT_CE(3, 7)
+                PT_CE(1, 5) PT_CE(2, 6)
+                PT_CE(1, 4) PT_CE(3, 6)
+                PT_CE(2, 4) PT_CE(3, 5)
+                PT_CE(3, 4)
+#endif
 #undef PT_CE
                 // ... go to the nearest, stack the others farthest first
 #pragma unroll
-                for (int k = 3; k >= 1; --k) {
+                for (int k = W - 1; k >= 1; --k) {
                     if (tk[k] < __builtin_inff()) {
                         if (sp < PT_BVH_LDS_STACK) stk[sp * PT_TRACE_THREADS] = lk[k];
                         else if (sp < PT_BVH_STACK) ovf[sp - PT_BVH_LDS_STACK] = lk[k];
