@@ -1471,7 +1471,10 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (start) {
                     // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
                     // boxes' margin); a zero component gives +-Inf
-                    ix = __builtin_amdgcn_rcpf(s.d.x); iy = __builtin_amdgcn_rcpf(s.d.y); iz = __builtin_amdgcn_rcpf(s.d.z);
+                    // (clamped to +-2^60: a zero component keeps its sign and the products stay finite)
+                    ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.x), -0x1p60f, 0x1p60f);
+                    iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.y), -0x1p60f, 0x1p60f);
+                    iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.z), -0x1p60f, 0x1p60f);
                     cur = 0u;
                     sp = 0;
                     budget = 2u * (unsigned)ntri;
@@ -1525,19 +1528,23 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     qw[4 * k] = v.x; qw[4 * k + 1] = v.y;
                     if (4 * k + 2 < (6 * W + 3) / 4) { qw[4 * k + 2] = v.z; qw[4 * k + 3] = v.w; }
                 }
+                // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
+                // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
+                // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
+                const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
+                const float cx = (ox - s.o.x) * ix, cy = (oy - s.o.y) * iy, cz = (oz - s.o.z) * iz;
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     // byte j of the 6 W (little endian): (qw[j >> 2] >> (8 * (j & 3))) & 255
-                    float4 bmin, bmax;
-                    bmin.x = pt_fma((float)((qw[(6 * k + 0) >> 2] >> (8 * ((6 * k + 0) & 3))) & 255u), sx, ox);
-                    bmin.y = pt_fma((float)((qw[(6 * k + 1) >> 2] >> (8 * ((6 * k + 1) & 3))) & 255u), sy, oy);
-                    bmin.z = pt_fma((float)((qw[(6 * k + 2) >> 2] >> (8 * ((6 * k + 2) & 3))) & 255u), sz, oz);
-                    bmax.x = pt_fma((float)((qw[(6 * k + 3) >> 2] >> (8 * ((6 * k + 3) & 3))) & 255u), sx, ox);
-                    bmax.y = pt_fma((float)((qw[(6 * k + 4) >> 2] >> (8 * ((6 * k + 4) & 3))) & 255u), sy, oy);
-                    bmax.z = pt_fma((float)((qw[(6 * k + 5) >> 2] >> (8 * ((6 * k + 5) & 3))) & 255u), sz, oz);
-                    bmin.w = bmax.w = 0.0f;
-                    float tn;
-                    const bool hit = pt_slab(bmin, bmax, s.o, ix, iy, iz, tmax, tn) & (lk[k] != PT_BVH_ABSENT);
+                    const float t1x = pt_fma((float)((qw[(6 * k + 0) >> 2] >> (8 * ((6 * k + 0) & 3))) & 255u), kx, cx);
+                    const float t1y = pt_fma((float)((qw[(6 * k + 1) >> 2] >> (8 * ((6 * k + 1) & 3))) & 255u), ky, cy);
+                    const float t1z = pt_fma((float)((qw[(6 * k + 2) >> 2] >> (8 * ((6 * k + 2) & 3))) & 255u), kz, cz);
+                    const float t2x = pt_fma((float)((qw[(6 * k + 3) >> 2] >> (8 * ((6 * k + 3) & 3))) & 255u), kx, cx);
+                    const float t2y = pt_fma((float)((qw[(6 * k + 4) >> 2] >> (8 * ((6 * k + 4) & 3))) & 255u), ky, cy);
+                    const float t2z = pt_fma((float)((qw[(6 * k + 5) >> 2] >> (8 * ((6 * k + 5) & 3))) & 255u), kz, cz);
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fminf(__builtin_fmaxf(t1z, t2z), tmax));
+                    const bool hit = (tn <= tf) & (lk[k] != PT_BVH_ABSENT);
                     tk[k] = hit ? tn : __builtin_inff();
                 }
                 // nearest first: sort the (distance, link) pairs (a 5- or 19-exchange network; misses sink to the end) ...
