@@ -232,60 +232,58 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     }
 }
 
-// the triangles in leaf order, 48 bytes each, carrying their index: a leaf is one contiguous run of records
-__global__ void pt_bvh_leaf_tris_kernel(const unsigned long long* __restrict__ keys, int n, const PtPrepTriangle* __restrict__ prep,
-                                        PtLeafTri* __restrict__ ltris)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const unsigned tri = (unsigned)keys[k];
-    const PtPrepTriangle t = prep[tri];
-    PtLeafTri r;
-    for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
-    r.index = tri;
-    r.pad[0] = r.pad[1] = 0.0f;
-    ltris[k] = r;
-}
-
 __device__ __forceinline__ float pt_bvh_decode(unsigned q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
 
-// binary fp32 nodes -> the one-line PT_BVH_WIDTH-child nodes the traversal reads (PtBvhWideNode).  One thread per binary
-// node; nodes whose depth is not a multiple of PT_BVH_LEVELS are absorbed into an ancestor and write nothing.
-__global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n, PtBvhWideNode* __restrict__ out)
+// ---- binary fp32 nodes -> the eight-child nodes the traversal reads (PtBvh8Node, pt_kernels.h) -------------------
+// Every binary node at a depth that is a multiple of three is the root of one eight-child node.  Three passes, one
+// thread per binary node, no level-by-level dependency:
+//   count:  how many of the (present) children are nodes / leaves;            then an exclusive scan of the counts
+//   assign: the node children of P get the consecutive new indices 1 + scan_nodes(P) + rank (rank in slot order)
+//   emit:   P writes its node at its new index and its leaf children's records at scan_leaves(P) + rank
+// (a child whose box is empty -- a subtree of triangles kept out of the hierarchy or with non-finite vertices -- is
+// dropped: its slot stays empty and nothing below it is ever written or read)
+struct PtGather8 {
+    int m;              // present children
+    unsigned link[8];   // binary links: node index, or 0x80000000 | sorted position
+    float lo[8][3], hi[8][3];
+    int slot[8];        // the slot each child sits in (pt_bvh8_gather assigns them)
+};
+
+__device__ __forceinline__ int pt_bvh_depth(const int* __restrict__ parent, int i)
 {
-    constexpr int W = PT_BVH_WIDTH;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
     int depth = 0;
     for (int p = parent[i]; p >= 0 && depth < 256; p = parent[p]) ++depth;
-    if (depth % PT_BVH_LEVELS) return;
-    // the (up to W) children: the binary node's two, then PT_BVH_LEVELS - 1 times every internal one replaced by its
-    // two (a leaf stays); in-order, so the children stay in Morton order
-    unsigned link[W];
-    float lo[W][3], hi[W][3];
-    int m = 0;
+    return depth;
+}
+
+__device__ void pt_bvh8_gather(const PtBvhNode* __restrict__ wide, int i, PtGather8& g)
+{
+    unsigned link[8];
+    float lo[8][3], hi[8][3];
+    int m = 2;
     {
         const PtBvhNode w = wide[i];
         link[0] = w.link_l; link[1] = w.link_r;
         for (int a = 0; a < 3; ++a) { lo[0][a] = w.lmin[a]; hi[0][a] = w.lmax[a]; lo[1][a] = w.rmin[a]; hi[1][a] = w.rmax[a]; }
-        m = 2;
     }
-    for (int round = 1; round < PT_BVH_LEVELS; ++round) {
-        unsigned l2[W];
-        float lo2[W][3], hi2[W][3];
+    for (int round = 1; round < 3; ++round) {
+        unsigned l2[8];
+        float lo2[8][3], hi2[8][3];
         int m2 = 0;
         for (int k = 0; k < m; ++k) {
-            if (link[k] & 0x80000000u) {
+            bool present = true;
+            for (int a = 0; a < 3; ++a) present = present && (lo[k][a] <= hi[k][a]);
+            if ((link[k] & 0x80000000u) || !present) {  // a leaf stays; so does an empty child (dropped below)
                 l2[m2] = link[k];
                 for (int a = 0; a < 3; ++a) { lo2[m2][a] = lo[k][a]; hi2[m2][a] = hi[k][a]; }
                 ++m2;
             } else {
-                const PtBvhNode g = wide[link[k]];
-                l2[m2] = g.link_l;
-                for (int a = 0; a < 3; ++a) { lo2[m2][a] = g.lmin[a]; hi2[m2][a] = g.lmax[a]; }
+                const PtBvhNode c = wide[link[k]];
+                l2[m2] = c.link_l;
+                for (int a = 0; a < 3; ++a) { lo2[m2][a] = c.lmin[a]; hi2[m2][a] = c.lmax[a]; }
                 ++m2;
-                l2[m2] = g.link_r;
-                for (int a = 0; a < 3; ++a) { lo2[m2][a] = g.rmin[a]; hi2[m2][a] = g.rmax[a]; }
+                l2[m2] = c.link_r;
+                for (int a = 0; a < 3; ++a) { lo2[m2][a] = c.rmin[a]; hi2[m2][a] = c.rmax[a]; }
                 ++m2;
             }
         }
@@ -295,28 +293,114 @@ __global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const
             for (int a = 0; a < 3; ++a) { lo[k][a] = lo2[k][a]; hi[k][a] = hi2[k][a]; }
         }
     }
-    for (int k = m; k < W; ++k) {
-        link[k] = PT_BVH_ABSENT;
-        for (int a = 0; a < 3; ++a) { lo[k][a] = 3.0e38f; hi[k][a] = -3.0e38f; }
-    }
-    bool present[W];
-    for (int k = 0; k < W; ++k) present[k] = false;
+    g.m = 0;
     for (int k = 0; k < m; ++k) {
-        bool ok = true;
-        for (int a = 0; a < 3; ++a) ok = ok && (lo[k][a] <= hi[k][a]);  // empty (3e38, -3e38) or NaN boxes are absent
-        present[k] = ok;
-        if (!ok) link[k] = PT_BVH_ABSENT;
+        bool present = true;
+        for (int a = 0; a < 3; ++a) present = present && (lo[k][a] <= hi[k][a]);  // empty (3e38, -3e38) or NaN boxes are dropped
+        if (!present) continue;
+        g.link[g.m] = link[k];
+        for (int a = 0; a < 3; ++a) { g.lo[g.m][a] = lo[k][a]; g.hi[g.m][a] = hi[k][a]; }
+        ++g.m;
     }
-    PtBvhWideNode o;
+    // slots: the child's position relative to the centre of the children's union decides the octant it would like;
+    // greedy assignment, best (child, slot) pair first (deterministic: both passes that call this get the same slots)
+    float pc[3];
+    for (int a = 0; a < 3; ++a) {
+        float l = 3.0e38f, h = -3.0e38f;
+        for (int k = 0; k < g.m; ++k) { l = fminf(l, g.lo[k][a]); h = fmaxf(h, g.hi[k][a]); }
+        pc[a] = 0.5f * l + 0.5f * h;
+    }
+    unsigned used = 0u;
+    for (int k = 0; k < 8; ++k) g.slot[k] = -1;
+    for (int it = 0; it < g.m; ++it) {
+        float best = -__builtin_inff();
+        int bc = -1, bs = -1;
+        for (int k = 0; k < g.m; ++k) {
+            if (g.slot[k] >= 0) continue;
+            float off[3];
+            for (int a = 0; a < 3; ++a) off[a] = (0.5f * g.lo[k][a] + 0.5f * g.hi[k][a]) - pc[a];
+            for (int sl = 0; sl < 8; ++sl) {
+                if (used & (1u << sl)) continue;
+                const float cost = ((sl & 1) ? off[0] : -off[0]) + ((sl & 2) ? off[1] : -off[1]) + ((sl & 4) ? off[2] : -off[2]);
+                if (bc < 0 || cost > best) { best = cost; bc = k; bs = sl; }
+            }
+        }
+        g.slot[bc] = bs;
+        used |= 1u << bs;
+    }
+}
+
+__global__ void pt_bvh8_count_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n, unsigned long long* __restrict__ cnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    unsigned long long c = 0ull;
+    if (pt_bvh_depth(parent, i) % 3 == 0) {
+        PtGather8 g;
+        pt_bvh8_gather(wide, i, g);
+        for (int k = 0; k < g.m; ++k) c += (g.link[k] & 0x80000000u) ? (1ull << 32) : 1ull;
+    }
+    cnt[i] = c;  // node children | leaf children << 32
+}
+
+__global__ void pt_bvh8_assign_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n,
+                                      const unsigned long long* __restrict__ base, int* __restrict__ newidx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || pt_bvh_depth(parent, i) % 3 != 0) return;
+    PtGather8 g;
+    pt_bvh8_gather(wide, i, g);
+    int rank = 0;
+    for (int sl = 0; sl < 8; ++sl)
+        for (int k = 0; k < g.m; ++k)
+            if (g.slot[k] == sl && !(g.link[k] & 0x80000000u)) newidx[g.link[k]] = 1 + (int)(unsigned)base[i] + rank++;
+}
+
+// keys: the sorted triangle keys (the leaf at sorted position c is triangle (unsigned)keys[c])
+__global__ void pt_bvh8_emit_kernel(const PtBvhNode* __restrict__ wide, const int* __restrict__ parent, int n,
+                                    const unsigned long long* __restrict__ base, const int* __restrict__ newidx,
+                                    const unsigned long long* __restrict__ keys, const PtPrepTriangle* __restrict__ prep,
+                                    PtBvh8Node* __restrict__ out, PtLeafTri* __restrict__ ltris)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || pt_bvh_depth(parent, i) % 3 != 0) return;
+    const int my = i == 0 ? 0 : newidx[i];
+    if (my < 0) return;  // below a dropped child: unreachable
+    PtGather8 g;
+    pt_bvh8_gather(wide, i, g);
+    PtBvh8Node o;
+    o.child_base = 1u + (unsigned)base[i];
+    o.tri_base = (unsigned)(base[i] >> 32);
+    unsigned imask = 0u, lmask = 0u;
+    for (int k = 0; k < g.m; ++k) {
+        if (g.link[k] & 0x80000000u) lmask |= 1u << g.slot[k];
+        else imask |= 1u << g.slot[k];
+    }
+    o.lmask = lmask;
+    o.pad0 = 0u;
+    for (unsigned k = 0; k < sizeof o.pad / sizeof o.pad[0]; ++k) o.pad[k] = 0u;
+    // the leaf children's records, in slot order
+    {
+        unsigned rank = 0u;
+        for (int sl = 0; sl < 8; ++sl)
+            for (int k = 0; k < g.m; ++k)
+                if (g.slot[k] == sl && (g.link[k] & 0x80000000u)) {
+                    const unsigned tri = (unsigned)keys[g.link[k] & 0x7fffffffu];
+                    const PtPrepTriangle t = prep[tri];
+                    PtLeafTri r;
+                    for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
+                    r.index = tri;
+                    r.pad[0] = r.pad[1] = 0.0f;
+                    ltris[o.tri_base + rank++] = r;
+                }
+    }
     unsigned ex[3] = { 1u, 1u, 1u };
     for (int a = 0; a < 3; ++a) {
         float org = 3.0e38f, top = -3.0e38f;
-        for (int k = 0; k < W; ++k)
-            if (present[k]) { org = fminf(org, lo[k][a]); top = fmaxf(top, hi[k][a]); }
+        for (int k = 0; k < g.m; ++k) { org = fminf(org, g.lo[k][a]); top = fmaxf(top, g.hi[k][a]); }
         if (!(org <= top)) { org = 0.0f; top = 0.0f; }
         o.origin[a] = org;
-        // smallest power of two `step` with decode(255) >= top; then every bound rounded outward and CHECKED with the
-        // traversal's own decode expression
+        // smallest power of two `step` with decode(255) >= top; then every bound rounded outward and CHECKED by decoding
         int e2 = -126;
         const float ext = top - org;
         if (ext > 0.0f) (void)frexpf(ext / 255.0f, &e2);
@@ -325,57 +409,67 @@ __global__ void pt_bvh_collapse_kernel(const PtBvhNode* __restrict__ wide, const
         for (;;) {
             const float step = __uint_as_float((unsigned)be << 23);
             bool ok = true;
-            for (int k = 0; k < W && ok; ++k) {
-                unsigned ql = 255u, qh = 0u;  // an absent child: inverted (and its link says so)
-                if (present[k]) {
-                    float fl = floorf((lo[k][a] - org) / step), fh = ceilf((hi[k][a] - org) / step);
-                    fl = fminf(fmaxf(fl, 0.0f), 255.0f);
-                    fh = fminf(fmaxf(fh, 0.0f), 255.0f);
-                    ql = (unsigned)fl; qh = (unsigned)fh;
-                    while (ql > 0u && pt_bvh_decode(ql, step, org) > lo[k][a]) --ql;
-                    while (qh < 255u && pt_bvh_decode(qh, step, org) < hi[k][a]) ++qh;
-                    if (pt_bvh_decode(ql, step, org) > lo[k][a] || pt_bvh_decode(qh, step, org) < hi[k][a]) ok = false;
-                }
-                o.q[6 * k + a] = (uint8_t)ql;
-                o.q[6 * k + 3 + a] = (uint8_t)qh;
+            for (int sl = 0; sl < 8; ++sl) { o.qlo[a][sl] = 255; o.qhi[a][sl] = 0; }  // an empty slot: inverted (and in neither mask)
+            for (int k = 0; k < g.m && ok; ++k) {
+                float fl = floorf((g.lo[k][a] - org) / step), fh = ceilf((g.hi[k][a] - org) / step);
+                fl = fminf(fmaxf(fl, 0.0f), 255.0f);
+                fh = fminf(fmaxf(fh, 0.0f), 255.0f);
+                unsigned ql = (unsigned)fl, qh = (unsigned)fh;
+                while (ql > 0u && pt_bvh_decode(ql, step, org) > g.lo[k][a]) --ql;
+                while (qh < 255u && pt_bvh_decode(qh, step, org) < g.hi[k][a]) ++qh;
+                if (pt_bvh_decode(ql, step, org) > g.lo[k][a] || pt_bvh_decode(qh, step, org) < g.hi[k][a]) ok = false;
+                o.qlo[a][g.slot[k]] = (uint8_t)ql;
+                o.qhi[a][g.slot[k]] = (uint8_t)qh;
             }
             if (ok || be >= 254) break;  // (be = 254 always suffices for finite boxes: 255 x 2^127 spans binary32)
             ++be;
         }
         ex[a] = (unsigned)be;
     }
-    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-    for (int k = 0; k < W; ++k) o.link[k] = link[k];
-    for (unsigned k = 0; k < sizeof o.pad / sizeof o.pad[0]; ++k) o.pad[k] = 0u;
-    out[i] = o;
+    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+    out[my] = o;
 }
 
 }  // namespace
 
 size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ptk_bvh_leaf_count(ntri) - 1 : 0; }
 
+static size_t pt_bvh_scan_bytes(int n)
+{
+    size_t bytes = 0;
+    unsigned long long* nullk = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, nullk, nullk, n);
+    return bytes;
+}
+
 size_t ptk_bvh_temp_bytes(int ntri)
 {
     size_t cub = 0;
     unsigned long long* nullk = nullptr;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
+    const size_t scan = pt_bvh_scan_bytes(ntri);
     const size_t n = (size_t)ntri;
-    // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], cub temp
-    return 16 * n + 8 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + cub + 1024 + sizeof(PtBvhNode) * n + 512;  // + leaf keys, the fp32 nodes
+    // keys, sorted keys, leaf keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], the fp32 nodes, child counts and
+    // their scan, new indices, cub temp (sort and scan use it in turn)
+    return 24 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + sizeof(PtBvhNode) * n + 16 * n + 4 * n + (cub > scan ? cub : scan) + 2048;
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhWideNode* nodes4, PtLeafTri* ltris,
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes8, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
+    static_assert(PT_BVH_CLUSTER_SHIFT == 0, "one triangle per leaf");
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
     char* p = (char*)temp;
     unsigned long long* keys = (unsigned long long*)p; p += 8 * n;
     unsigned long long* sorted = (unsigned long long*)p; p += 8 * n;
     unsigned long long* lkeys = (unsigned long long*)p; p += 8 * n;
+    unsigned long long* cnt = (unsigned long long*)p; p += 8 * n;
+    unsigned long long* base = (unsigned long long*)p; p += 8 * n;
     int* parent = (int*)p; p += 4 * 2 * n;
     int* right_child = (int*)p; p += 4 * n;
     int* flags = (int*)p; p += 4 * n;
+    int* newidx = (int*)p; p += 4 * n;
     unsigned* bounds = (unsigned*)p; p += 64;
     p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     PtBvhNode* nodes = (PtBvhNode*)p; p += sizeof(PtBvhNode) * n;  // fp32 nodes: refit works on these, then compressed
@@ -386,6 +480,7 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipError_t e = hipMemcpyAsync(bounds, init, sizeof init, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(flags, 0, 4 * n, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(newidx, 0xff, 4 * n, s)) != hipSuccess) return e;  // -1: not reachable
     const dim3 blk(256), grd((ntri + 255) / 256);
     hipLaunchKernelGGL(pt_bvh_bounds_kernel, grd, blk, 0, s, raw, ntri, bounds);
     hipLaunchKernelGGL(pt_bvh_threshold_kernel, dim3(1), dim3(1), 0, s, bounds);
@@ -398,7 +493,9 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipLaunchKernelGGL(pt_bvh_leaf_keys_kernel, lgrd, blk, 0, s, sorted, nleaves, shift, lkeys);
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, lkeys, nleaves, nodes, parent, right_child);
     hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, ntri, shift, nleaves, bounds, nodes, parent, right_child, flags);
-    hipLaunchKernelGGL(pt_bvh_collapse_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, nodes4);
-    hipLaunchKernelGGL(pt_bvh_leaf_tris_kernel, grd, blk, 0, s, sorted, ntri, prep, ltris);
+    hipLaunchKernelGGL(pt_bvh8_count_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, cnt);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(p, cub, cnt, base, nleaves - 1, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pt_bvh8_assign_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, base, newidx);
+    hipLaunchKernelGGL(pt_bvh8_emit_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, base, newidx, sorted, prep, nodes8, ltris);
     return hipGetLastError();
 }

@@ -34,41 +34,40 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
-// The node the trace kernel walks: ONE cache line, PT_BVH_WIDTH children.  The search is bound by the line requests
-// its L2 misses make (profiles/r02/pmc_soup_lbvh_32B_nodes.txt: 46 % L2 hit rate, 3.9 TB/s of 64-byte fetches of which
-// a two-child 32-byte node used half; tools/ubench_gather: dependent random reads of a 70 MB table run at 75 G/s for
-// 64-byte records and at 86 G/s for aligned 128-byte records), so a node is exactly one such line and all of it is
-// used: the binary radix tree is collapsed PT_BVH_LEVELS levels at a time (every binary node at a depth that is a
-// multiple of PT_BVH_LEVELS becomes a node whose children are its descendants PT_BVH_LEVELS further down, or shallower
-// ones that are leaves), nodes keep their binary indices (the other levels' slots stay empty).  The children's boxes
-// are quantised to 8 bits per coordinate in the node's own frame (origin = lower corner of their union, one
-// power-of-two step per axis), rounded OUTWARD and verified at build time with the very expression the traversal
-// decodes them with (fma(q, step, origin)): the decoded box contains the fp32 box.
-#ifndef PT_BVH_WIDTH
-#define PT_BVH_WIDTH 4
-#endif
-#if PT_BVH_WIDTH == 4
-#define PT_BVH_LEVELS 2
-#elif PT_BVH_WIDTH == 8
-#define PT_BVH_LEVELS 3
-#else
-#error "PT_BVH_WIDTH is 4 (64-byte nodes) or 8 (128-byte nodes)"
-#endif
-struct alignas(16 * PT_BVH_WIDTH) PtBvhWideNode {
+// The node the trace kernel walks: EIGHT children in 80 bytes of a 128-byte aligned slot, one cache line, one request
+// (tools/ubench_gather, profiles/r02/ubench_gather.txt: dependent random reads of a 70 MB table run at 75 G/s for 64-byte
+// records and at 86 G/s for aligned 128-byte records; the search is bound by its line requests and by VALU issue in
+// about equal parts, so a node holds as many children as a line allows and costs as few instructions as possible --
+// after Ylitie, Karras, Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017):
+//   * the binary radix tree is collapsed three levels at a time: every binary node at a depth that is a multiple of
+//     three becomes a node whose children are its descendants three levels down, or shallower ones that are leaves;
+//   * children that are nodes are stored CONSECUTIVELY (child_base + rank among the node children, in slot order),
+//     children that are leaves have their 48-byte records consecutively in the leaf array (tri_base + rank): no links;
+//   * a child sits in the slot whose three bits say on which side of the node's centre it lies (x = bit 0, y = bit 1,
+//     z = bit 2; greedy assignment), so "slot XOR (ray direction's octant)" orders the children front to back for
+//     every ray without a sort;
+//   * boxes: 8 bits per coordinate in the node's own frame (origin = lower corner of the children's union, one
+//     power-of-two step per axis), rounded OUTWARD and verified at build time by decoding (fma(q, step, origin) contains
+//     the fp32 box); stored per axis (qlo[axis][slot], qhi[axis][slot]) so the ray's direction signs pick the near and
+//     far planes of all eight children with four selects per axis; an empty slot holds an inverted box (255, 0) AND is
+//     missing from both masks.
+struct alignas(128) PtBvh8Node {
     float origin[3];
-    uint32_t meta;                  // step exponents (biased as in binary32) x | y << 8 | z << 16
-    uint32_t link[PT_BVH_WIDTH];    // child k: node index, 0x80000000 | leaf, or PT_BVH_ABSENT
-    uint8_t q[6 * PT_BVH_WIDTH];    // child k: min xyz at q[6k], max xyz at q[6k + 3]
-    uint32_t pad[(6 * PT_BVH_WIDTH - 16) / 4];
+    uint32_t meta;        // step exponents (biased as in binary32) x | y << 8 | z << 16 | imask << 24
+    uint32_t child_base;  // the child in slot s (imask bit s set) is node child_base + popcount(imask & ((1 << s) - 1))
+    uint32_t tri_base;    // the leaf in slot s (lmask bit s set) is record tri_base + popcount(lmask & ((1 << s) - 1))
+    uint32_t lmask;       // slots that hold leaves (low 8 bits); imask (meta >> 24): slots that hold nodes
+    uint32_t pad0;
+    uint8_t qlo[3][8];    // [axis][slot]
+    uint8_t qhi[3][8];
+    uint32_t pad[12];
 };
-static_assert(sizeof(PtBvhWideNode) == 16 * PT_BVH_WIDTH, "bvh node layout");
-#define PT_BVH_ABSENT 0xffffffffu  // nothing to visit in this slot (fewer children than slots; non-finite triangles;
-                                   // triangles kept out of the hierarchy)
+static_assert(sizeof(PtBvh8Node) == 128, "bvh node layout");
 
-// A LEAF of the hierarchy is a run of 1 << PT_BVH_CLUSTER_SHIFT consecutive triangles of the Morton order, walked
-// one triangle per step.  Leaf records are compact: 48 bytes, three 16-byte loads.
-#define PT_BVH_CLUSTER_SHIFT 0  // (2 = four triangles per leaf was measured: the 10^6-triangle soup's leaf boxes grow 9x in
-                                // cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s)
+// A LEAF of the hierarchy is ONE triangle: a compact 48-byte record, three 16-byte loads.  (Leaves of four
+// consecutive triangles of the Morton order were measured in round 2: the 10^6-triangle soup's leaf boxes grow 9x in
+// cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s.)
+#define PT_BVH_CLUSTER_SHIFT 0
 #define PT_BVH_CLUSTER (1 << PT_BVH_CLUSTER_SHIFT)
 struct PtLeafTri {
     float p1[3], e1[3], e2[3];  // as in PtPrepTriangle
@@ -101,10 +100,10 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvhWideNode* bvh;        // accel = BVH: four-child nodes at the binary tree's even-depth indices, root 0
-    const PtLeafTri* ltris;       // accel = BVH: the triangles in Morton-sorted order; leaf c holds [c << shift, (c + 1) << shift)
-    int32_t bvh_shift;            //              log2(triangles per leaf): PT_BVH_CLUSTER_SHIFT, or 0 for tiny scenes
-    int32_t bvh_leaves;           //              number of leaves; the hierarchy has bvh_leaves - 1 nodes, root 0
+    const PtBvh8Node* bvh;        // accel = BVH: eight-child nodes, root 0, every node's node children consecutive
+    const PtLeafTri* ltris;       // accel = BVH: the leaf records, every node's leaf children consecutive
+    int32_t bvh_shift;            //              (unused: one triangle per leaf)
+    int32_t bvh_leaves;           //              number of leaves; the hierarchy has at most bvh_leaves - 1 nodes
     const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
     const int32_t* bigidx;        //              their triangle indices, ascending
     int32_t nbig;
@@ -146,7 +145,7 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
 // nodes[ptk_bvh_leaf_count(ntri) - 1] and ltris[ntri] (device memory) receive the hierarchy the trace kernel walks
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvhWideNode* nodes, PtLeafTri* ltris,
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
 static inline int ptk_bvh_shift(int ntri) { return ntri >= 4 * PT_BVH_CLUSTER ? PT_BVH_CLUSTER_SHIFT : 0; }
 static inline int ptk_bvh_leaf_count(int ntri) { const int sh = ptk_bvh_shift(ntri); return (ntri + (1 << sh) - 1) >> sh; }

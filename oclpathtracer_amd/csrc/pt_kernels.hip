@@ -1338,32 +1338,41 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 }
 
 // ---- the LBVH trace kernel -------------------------------------------------------------------------
-// Lane = path, and every lane walks its own ray through the hierarchy (near child first, far child on a per-lane
-// stack) -- but rays differ wildly in how many nodes they enter, so a wave that waits for its slowest lane before
-// shading runs the search at a third of its lanes (round 1: 34 %).  Here the search is a per-lane STATE that
-// survives the shading phase: the wave steps all traversing lanes together, and as soon as no more than
-// PT_BVH_REFILL of them are still traversing, the finished lanes are shaded, dead ones take new samples, and all of
-// them start their next search while the stragglers simply keep theirs.  Lane occupancy of the search stays
-// between PT_BVH_REFILL/64 and 1.
-//   * per-lane stack: PT_BVH_LDS_STACK entries in LDS (entry-major: conflict-free), deeper ones in a private array;
+// Lane = path, and every lane walks its own ray through the hierarchy -- but rays differ wildly in how many nodes they
+// enter, so a wave that waits for its slowest lane before shading runs the search at a third of its lanes (round 1:
+// 34 %).  Here the search is a per-lane STATE that survives the shading phase: the wave steps all traversing lanes
+// together, and as soon as no more than PT_BVH_REFILL of them are still traversing, the finished lanes are shaded,
+// dead ones take new samples, and all of them start their next search while the stragglers simply keep theirs.
+//   * the hierarchy: eight-child nodes of 80 bytes in 128-byte slots (PtBvh8Node, pt_kernels.h; built by pt_bvh.hip),
+//     one line request per node.  The search is bound by line requests and by VALU issue in about equal parts
+//     (profiles/r02/ubench_gather.txt), so the node step is built for few instructions: entry / exit distances are one
+//     FMA per plane straight from the quantised bytes, the ray's direction signs select the near and far planes of all
+//     eight children at once, the children's slots encode their octant so "slot XOR ray octant" is the front-to-back
+//     order (no sort), and the hits of a node travel as ONE stack entry (base index, hit mask) instead of one per child;
+//   * a lane's state: the current GROUP of node children still to enter (gbase, gm = hits in priority order | imask << 8),
+//     the leaf children still to test (tbase, tm = hits by slot | lmask << 8), and a stack of earlier groups
+//     (PT_BVH_LDS_STACK entries in LDS, entry-major: conflict-free; deeper ones in a private array: a radix tree over
+//     64-bit keys has at most 64 levels = 22 levels of eight-child nodes, one entry each);
+//   * one wave step = a NODE phase (every lane without pending leaves enters its next node) and, when at least
+//     PT_BVH_TRI_LANES lanes hold pending leaves or nobody can enter a node, a TRIANGLE phase (one exact test per such
+//     lane): with 64 incoherent lanes some lane meets a leaf at nearly every step, and running the ~70-instruction
+//     triangle test for a handful of lanes each time cost more than letting them wait a step or two;
 //   * the triangles the builder kept out of the hierarchy (pt_bvh.hip: the few that span the scene) are searched
 //     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
-//   * the search is bound by the line requests its L2 misses make, so a node is one line holding PT_BVH_WIDTH children
-//     (PtBvhWideNode: the binary radix tree collapsed PT_BVH_LEVELS levels at a time, 8-bit boxes in the node's own
-//     frame, conservative by construction), visited nearest first; a leaf is a 48-byte record of the Morton-sorted copy
-//     of the triangles;
-//   * every link is visited at most once; a step budget and index checks make a damaged hierarchy end the
-//     search instead of hanging or faulting the GPU.
+//   * a step budget and index checks make a damaged hierarchy end the search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
-// triangles tested (both per lane), traversal steps of the waves.  Never the timed kernel.
-// a radix tree over 64-bit keys has at most 64 levels = 32 levels of four-child nodes, each of which stacks at most
-// three children (22 levels of eight-child nodes: seven each)
-#define PT_BVH_STACK (PT_BVH_WIDTH == 4 ? 96 : 160)
+// triangles tested (both per lane), phases executed by the waves.  Never the timed kernel.
+#ifndef PT_BVH_STACK
+#define PT_BVH_STACK 48  // (an overflow array of fewer than 64 dwords is promoted to registers: 126 VGPRs)
+#endif
 #ifndef PT_BVH_LDS_STACK
-#define PT_BVH_LDS_STACK 24
+#define PT_BVH_LDS_STACK 8
 #endif
 #ifndef PT_BVH_REFILL
 #define PT_BVH_REFILL 40
+#endif
+#ifndef PT_BVH_TRI_LANES
+#define PT_BVH_TRI_LANES 8
 #endif
 
 // dead lanes take the next samples of the wave's range, one by one (no coherence to keep here: the search dominates)
@@ -1402,14 +1411,23 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
     }
 }
 
+// hits by slot -> hits by priority: bit (slot ^ oct) of the result = bit slot of h (h: 8 bits)
+PTK_DEV unsigned pt_xor_permute8(unsigned h, unsigned oct)
+{
+    const unsigned h1 = ((h & 0x55u) << 1) | ((h >> 1) & 0x55u);
+    h = (oct & 1u) ? h1 : h;
+    const unsigned h2 = ((h & 0x33u) << 2) | ((h >> 2) & 0x33u);
+    h = (oct & 2u) ? h2 : h;
+    const unsigned h4 = ((h & 0x0fu) << 4) | ((h >> 4) & 0x0fu);
+    return (oct & 4u) ? h4 : h;
+}
+
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
     const int ntri = P.ntri;
     const unsigned n_nodes = (unsigned)P.bvh_leaves - 1u;
-    const unsigned shift = (unsigned)P.bvh_shift, tmask = (1u << shift) - 1u;
-    const unsigned DONE = 0x7fffffffu;  // (an internal-node link this large cannot exist)
     // LDS: the table of the triangles outside the hierarchy (pass 2 fetches its records per lane: pt_fetch_rec), the
     // stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
     {
@@ -1420,11 +1438,12 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         }
         __syncthreads();
     }
-    pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + threadIdx.x;  // entry e of this lane: stk[e * PT_TRACE_THREADS]
-    unsigned ovf[PT_BVH_STACK - PT_BVH_LDS_STACK];
+    // stack entry e of this lane: stk[2 e * PT_TRACE_THREADS] = base, stk[(2 e + 1) * PT_TRACE_THREADS] = masks
+    pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + threadIdx.x;
+    unsigned ovf[2 * (PT_BVH_STACK - PT_BVH_LDS_STACK)];
     PtTail tl;
     {
-        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + PT_BVH_LDS_STACK * PT_TRACE_THREADS +
+        pt_lds_u32* w = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + 2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS +
                         (threadIdx.x >> 6) * (128u + PT_TAIL_LIST);
         tl.keys = (pt_lds_u64*)w;
         tl.list = w + 128;
@@ -1446,8 +1465,9 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     // the search's state
     float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
     int hidx = -1;
-    unsigned cur = DONE;   // a link: internal node index, or 0x80000000 | position in the sorted order (a leaf is walked
-                           // one triangle per step: leaf c starts at position c << shift)
+    unsigned gbase = 0u, gm = 0u;  // the group of node children still to enter: hits by priority (8 bits) | imask << 8
+    unsigned tbase = 0u, tm = 0u;  // the leaf children still to test: hits by slot (8 bits) | lmask << 8
+    unsigned oct = 0u;             // bit a set: the ray runs towards +a (children on the low side come first)
     int sp = 0;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f;
     unsigned budget = 0u;
@@ -1469,118 +1489,113 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     if (start && hp >= 0) hidx = P.bigidx[hp];
                 }
                 if (start) {
-                    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the
-                    // boxes' margin); a zero component gives +-Inf
-                    // (clamped to +-2^60: a zero component keeps its sign and the products stay finite)
+                    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the boxes'
+                    // margin), clamped to +-2^60: a zero component keeps its sign and every product stays finite
                     ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.x), -0x1p60f, 0x1p60f);
                     iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.y), -0x1p60f, 0x1p60f);
                     iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.z), -0x1p60f, 0x1p60f);
-                    cur = 0u;
+                    oct = (ix < 0.0f ? 0u : 1u) | (iy < 0.0f ? 0u : 2u) | (iz < 0.0f ? 0u : 4u);
+                    // the root (node 0) as a group of one: slot 0, priority 0 ^ oct
+                    gbase = 0u;
+                    gm = (1u << oct) | (1u << 8);
+                    tbase = 0u; tm = 0u;
                     sp = 0;
-                    budget = 2u * (unsigned)ntri;
+                    budget = 2u * (unsigned)ntri + 64u;
                     trav = true;
                 }
             }
             if (__ballot(alive) == 0ull) break;
         }
-        // ---- one step of every traversing lane ---------------------------------------------------
-        if (TALLY) ++c_steps;
-        if (trav) {
-            const bool leaf = (cur & 0x80000000u) != 0u;
-            const unsigned idx = cur & 0x7fffffffu;
-            const bool in_range = leaf ? idx < (unsigned)ntri : idx < n_nodes;
-            unsigned next = DONE;
-            bool pop = true;
-            if (!in_range) {
-                sp = 0;
-            } else if (leaf) {
+        // ---- one step of the wave ----------------------------------------------------------------
+        const bool want_tri = trav && (tm & 255u) != 0u;
+        const bool want_node = trav && !want_tri;  // (such a lane holds a group or a stack entry: otherwise it was retired)
+        const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
+        const bool any_node = __ballot(want_node) != 0ull;
+        if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (!any_node && n_tri != 0u)) {
+            if (TALLY) ++c_steps;
+            if (want_tri) {
                 if (TALLY) ++c_leaves;
-                const float4* qp = reinterpret_cast<const float4*>(P.ltris + idx);
-                const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
-                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
-                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
-                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
-                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
-                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), s.o, s.d, tmax, hu, hv, hidx);
-                // the leaf's next triangle, if it has one
-                if ((idx & tmask) != tmask && idx + 1u < (unsigned)ntri) { next = cur + 1u; pop = false; }
-            } else {
-                if (TALLY) ++c_nodes;
-                constexpr int W = PT_BVH_WIDTH;
-                const uint4* np = reinterpret_cast<const uint4*>(P.bvh + idx);
-                uint4 nw[1 + W / 4 + (6 * W + 15) / 16];  // origin + meta | links | boxes (the padding is not fetched)
-#pragma unroll
-                for (int k = 0; k < 1 + W / 4 + (6 * W + 15) / 16; ++k) nw[k] = np[k];
-                const float ox = __uint_as_float(nw[0].x), oy = __uint_as_float(nw[0].y), oz = __uint_as_float(nw[0].z);
-                const unsigned meta = nw[0].w;
-                const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
-                            sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-                // the children: boxes decoded exactly as pt_bvh_collapse_kernel verified (fma(q, step, origin)),
-                // entry distance +Inf for a child that is absent or missed
-                unsigned qw[(6 * W + 3) / 4];  // 6 W bytes: child k at bytes 6k .. 6k+5
-                unsigned lk[W];
-                float tk[W];
-#pragma unroll
-                for (int k = 0; k < W / 4; ++k) { lk[4 * k] = nw[1 + k].x; lk[4 * k + 1] = nw[1 + k].y; lk[4 * k + 2] = nw[1 + k].z; lk[4 * k + 3] = nw[1 + k].w; }
-#pragma unroll
-                for (int k = 0; k < (6 * W + 15) / 16; ++k) {
-                    const uint4 v = nw[1 + W / 4 + k];
-                    qw[4 * k] = v.x; qw[4 * k + 1] = v.y;
-                    if (4 * k + 2 < (6 * W + 3) / 4) { qw[4 * k + 2] = v.z; qw[4 * k + 3] = v.w; }
+                const unsigned slot = (unsigned)__builtin_ctz(tm & 255u);
+                tm &= tm - 1u;  // (the lowest set bit is a hit bit: the hits are the low byte and not empty)
+                const unsigned idx = tbase + (unsigned)__popc((tm >> 8) & ((1u << slot) - 1u));
+                if (idx < (unsigned)ntri) {
+                    const float4* qp = reinterpret_cast<const float4*>(P.ltris + idx);
+                    const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+                    PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
+                    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+                    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+                    r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
+                    pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), s.o, s.d, tmax, hu, hv, hidx);
                 }
-                // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
-                // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
-                // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
-                const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
-                const float cx = (ox - s.o.x) * ix, cy = (oy - s.o.y) * iy, cz = (oz - s.o.z) * iz;
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    // byte j of the 6 W (little endian): (qw[j >> 2] >> (8 * (j & 3))) & 255
-                    const float t1x = pt_fma((float)((qw[(6 * k + 0) >> 2] >> (8 * ((6 * k + 0) & 3))) & 255u), kx, cx);
-                    const float t1y = pt_fma((float)((qw[(6 * k + 1) >> 2] >> (8 * ((6 * k + 1) & 3))) & 255u), ky, cy);
-                    const float t1z = pt_fma((float)((qw[(6 * k + 2) >> 2] >> (8 * ((6 * k + 2) & 3))) & 255u), kz, cz);
-                    const float t2x = pt_fma((float)((qw[(6 * k + 3) >> 2] >> (8 * ((6 * k + 3) & 3))) & 255u), kx, cx);
-                    const float t2y = pt_fma((float)((qw[(6 * k + 4) >> 2] >> (8 * ((6 * k + 4) & 3))) & 255u), ky, cy);
-                    const float t2z = pt_fma((float)((qw[(6 * k + 5) >> 2] >> (8 * ((6 * k + 5) & 3))) & 255u), kz, cz);
-                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
-                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fminf(__builtin_fmaxf(t1z, t2z), tmax));
-                    const bool hit = (tn <= tf) & (lk[k] != PT_BVH_ABSENT);
-                    tk[k] = hit ? tn : __builtin_inff();
-                }
-                // nearest first: sort the (distance, link) pairs (a 5- or 19-exchange network; misses sink to the end) ...
-#define PT_CE(a, b) { const bool sw = tk[b] < tk[a]; const float ta_ = sw ? tk[b] : tk[a], tb_ = sw ? tk[a] : tk[b]; \
-                      const unsigned la_ = sw ? lk[b] : lk[a], lb_ = sw ? lk[a] : lk[b]; tk[a] = ta_; tk[b] = tb_; lk[a] = la_; lk[b] = lb_; }
-#if PT_BVH_WIDTH == 4
-                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#else
-                PT_CE(0, 1) PT_CE(2, 3) PT_CE(4, 5) PT_CE(6, 7)
-                PT_CE(0, 2) PT_CE(1, 3) PT_CE(4, 6) PT_CE(5, 7)
-                PT_CE(1, 2) PT_CE(5, 6) PT_CE(0, 4) PT_CE(3, 7)
-                PT_CE(1, 5) PT_CE(2, 6)
-                PT_CE(1, 4) PT_CE(3, 6)
-                PT_CE(2, 4) PT_CE(3, 5)
-                PT_CE(3, 4)
-#endif
-#undef PT_CE
-                // ... go to the nearest, stack the others farthest first
-#pragma unroll
-                for (int k = W - 1; k >= 1; --k) {
-                    if (tk[k] < __builtin_inff()) {
-                        if (sp < PT_BVH_LDS_STACK) stk[sp * PT_TRACE_THREADS] = lk[k];
-                        else if (sp < PT_BVH_STACK) ovf[sp - PT_BVH_LDS_STACK] = lk[k];
-                        sp = sp < PT_BVH_STACK ? sp + 1 : sp;
-                    }
-                }
-                if (tk[0] < __builtin_inff()) { next = lk[0]; pop = false; }
+                --budget;
             }
-            if (pop && sp > 0) {
-                --sp;
-                next = sp < PT_BVH_LDS_STACK ? stk[sp * PT_TRACE_THREADS] : ovf[sp - PT_BVH_LDS_STACK];
-            }
-            cur = next;
-            --budget;
-            if (next == DONE || budget == 0u) trav = false;
         }
+        if (any_node) {
+            if (TALLY) ++c_steps;
+            if (want_node) {
+                if (TALLY) ++c_nodes;
+                if ((gm & 255u) == 0u) {  // (then sp > 0)
+                    sp = sp > 0 ? sp - 1 : 0;
+                    if (sp < PT_BVH_LDS_STACK) { gbase = stk[(2 * sp) * PT_TRACE_THREADS]; gm = stk[(2 * sp + 1) * PT_TRACE_THREADS]; }
+                    else { gbase = ovf[2 * (sp - PT_BVH_LDS_STACK)]; gm = ovf[2 * (sp - PT_BVH_LDS_STACK) + 1]; }
+                }
+                // the group's next child: highest priority first; its slot, its rank among the node children
+                const unsigned pr = 31u - (unsigned)__builtin_clz((gm & 255u) | 1u);
+                gm &= ~(1u << pr);
+                const unsigned slot = pr ^ oct;
+                const unsigned node = gbase + (unsigned)__popc((gm >> 8) & ((1u << slot) - 1u));
+                unsigned h = 0u, imask = 0u, lmask = 0u, cbase = 0u, lbase = 0u;
+                if (node < n_nodes) {
+                    const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
+                    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
+                    const unsigned meta = w0.w;
+                    const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
+                                sz = __uint_as_float(((meta >> 16) & 255u) << 23);
+                    imask = meta >> 24;
+                    cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
+                    // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
+                    // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
+                    // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
+                    const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
+                    const float cx = (__uint_as_float(w0.x) - s.o.x) * ix, cy = (__uint_as_float(w0.y) - s.o.y) * iy,
+                                cz = (__uint_as_float(w0.z) - s.o.z) * iz;
+                    // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
+                    // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
+                    const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
+                    const unsigned nx0 = px ? w2.x : w3.z, nx1 = px ? w2.y : w3.w, fx0 = px ? w3.z : w2.x, fx1 = px ? w3.w : w2.y;
+                    const unsigned ny0 = py ? w2.z : w4.x, ny1 = py ? w2.w : w4.y, fy0 = py ? w4.x : w2.z, fy1 = py ? w4.y : w2.w;
+                    const unsigned nz0 = pz ? w3.x : w4.z, nz1 = pz ? w3.y : w4.w, fz0 = pz ? w4.z : w3.x, fz1 = pz ? w4.w : w3.y;
+#define PT_B8(lo_, hi_, k) (float)((((k) < 4 ? (lo_) : (hi_)) >> (8 * ((k) & 3))) & 255u)
+#pragma unroll
+                    for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
+                        const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
+                        const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
+                        const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
+                        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+                        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tmax));
+                        h = pt_push_flag(h, PT_LANES(tn <= tf));
+                    }
+#undef PT_B8
+                }
+                const unsigned hn = h & imask, ht = h & lmask;
+                // the rest of the old group goes on the stack, the children just hit become the current group
+                if ((gm & 255u) != 0u && hn != 0u) {
+                    if (sp < PT_BVH_LDS_STACK) { stk[(2 * sp) * PT_TRACE_THREADS] = gbase; stk[(2 * sp + 1) * PT_TRACE_THREADS] = gm; }
+                    else if (sp < PT_BVH_STACK) { ovf[2 * (sp - PT_BVH_LDS_STACK)] = gbase; ovf[2 * (sp - PT_BVH_LDS_STACK) + 1] = gm; }
+                    sp = sp < PT_BVH_STACK ? sp + 1 : sp;
+                }
+                if (hn != 0u) {
+                    gbase = cbase;
+                    gm = pt_xor_permute8(hn, oct) | (imask << 8);
+                }
+                tbase = lbase;
+                tm = ht | (lmask << 8);
+                --budget;
+            }
+        }
+        // a lane with nothing left to enter or test has its closest hit
+        if (trav && ((tm & 255u) == 0u) && ((gm & 255u) == 0u) && sp == 0) trav = false;
+        if (trav && (int)budget <= 0) trav = false;
     }
 
     if (TALLY && P.stats) {
@@ -1832,7 +1847,7 @@ size_t ptk_trace_lds_bytes(int ntri)
 size_t ptk_trace_bvh_lds_bytes(void)
 {
     // the big-triangle table + the 256 lanes' stacks + per wave the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
-    return (size_t)PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE * 4 + (size_t)PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
+    return (size_t)PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE * 4 + (size_t)2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
 }
 
 int ptk_trace_bvh_blocks_per_cu(void)

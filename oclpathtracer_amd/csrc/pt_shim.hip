@@ -98,7 +98,7 @@ struct pt_device_s {
     int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
                                 // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
-    PtBvhWideNode* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
+    PtBvh8Node* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
     PtLeafTri* ltris;           // its leaves: the triangles in Morton order
     PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
     int* bigidx;
@@ -752,7 +752,7 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 {
     if (d->bvh_valid) return PT_OK;
     if (!d->bvh) {
-        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvhWideNode));
+        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
         if (e == hipSuccess) e = hipMalloc(&d->ltris, d->prep_capacity * sizeof(PtLeafTri));
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e)); }
     }
