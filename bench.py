@@ -45,8 +45,8 @@ F_ACCEPT, F_SHADE_DIFFUSE, F_SHADE_SPECULAR = 33.0, 120.0, 160.0
 BYTES_PER_SAMPLE = 32.0         # 16 B read + 16 B write of one float4 pixel (GenerateColors.cl:314-321)
 # LBVH search (configs[4]): per four-child node entered, four slab tests (6 sub, 6 mul, 12 min/max, 3 compares = 27
 # flop each) + ordering; per triangle tested the reference's full test (52, reach_t) -- DESIGN.md S4
-F_BVH_NODE, F_BVH_TRI = 120.0, 52.0  # a four-child node: 4 slab tests x 27 + ordering 12
-B_BVH_NODE, B_BVH_TRI = 64.0, 48.0   # one 64-byte node per node entered, one 48-byte leaf record per triangle tested
+F_BVH_NODE, F_BVH_TRI = 161.0, 52.0  # an eight-child node: 8 x (6 FMA + 6 min/max + 1 compare) + 9 for the node's frame
+B_BVH_NODE, B_BVH_TRI = 80.0, 48.0   # the 80 bytes read of a node's 128-byte slot per node entered, one 48-byte leaf record per triangle tested
 
 
 def pmc_traffic():
@@ -195,9 +195,11 @@ def bvh_tallies(dev, lib, shim, tris, mats, W, H, depth):
     finally:
         dev.setOption(shim.PT_OPT_BVH_TALLY, 0)
     rays = max(int(st[shim.PT_STAT_RAYS]), 1)
-    nodes, tris_, steps = int(st[shim.PT_STAT_BVH_NODES]), int(st[shim.PT_STAT_BVH_TRIS]), int(st[shim.PT_STAT_BVH_STEPS])
+    nodes, tris_ = int(st[shim.PT_STAT_BVH_NODES]), int(st[shim.PT_STAT_BVH_TRIS])
+    steps, tsteps = int(st[shim.PT_STAT_BVH_STEPS]), int(st[shim.PT_STAT_BVH_TRI_STEPS])
     return {"nodes_per_ray": nodes / rays, "tris_per_ray": tris_ / rays,
-            "search_lane_occupancy": (nodes + tris_) / max(64 * steps, 1)}
+            "node_phase_lane_occupancy": nodes / max(64 * steps, 1), "tri_phase_lane_occupancy": tris_ / max(64 * tsteps, 1),
+            "search_lane_occupancy": (nodes + tris_) / max(64 * (steps + tsteps), 1)}
 
 
 def soup_pmc_traffic():
@@ -226,7 +228,7 @@ def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):
              "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_,
              "traffic_basis": (src + ": measured bytes fetched beyond the L2 per ray x rays of this launch") if src else None,
              "measured_fetch_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-             "note": "algorithmic = 64 B per four-child node entered + 48 B per triangle tested + 12 B radiance per sample; the upper "
+             "note": "algorithmic = 80 B per eight-child node entered + 48 B per triangle tested + 12 B radiance per sample; the upper "
                      "tree levels are served by L1 / L2, so the algorithmic rate exceeds what crosses the L2's miss path "
                      "(`traffic`, measured): that path, 64-byte random fetches, is what bounds the kernel", **tally},
             {"bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,

@@ -245,9 +245,10 @@ int pt_local_rows(int height, int stripe_rows, int n_ranks, int rank);
 /* work counters accumulated by pt_render_frames when stats != NULL (uint64 each) */
 enum {
     PT_STAT_SAMPLES = 0, PT_STAT_RAYS = 1,
-    /* PT_OPT_BVH_TALLY renders only: box nodes entered and triangles tested (summed over the rays), traversal
-     * steps of the waves (one step moves every traversing lane of a wave by one node or triangle) */
-    PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_STEPS = 4,
+    /* PT_OPT_BVH_TALLY renders only: box nodes entered and triangles tested (summed over the rays), and the phases
+     * the waves executed for them (a node phase enters one node per participating lane, a triangle phase tests one
+     * triangle per participating lane) */
+    PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_STEPS = 4 /* node phases */, PT_STAT_BVH_TRI_STEPS = 5,
     PT_STAT_WORDS = 8
 };
 

@@ -1361,7 +1361,7 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 //     first, by the brute-force two-pass search over their own table, which also hands the traversal a tight tmax;
 //   * a step budget and index checks make a damaged hierarchy end the search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
-// triangles tested (both per lane), phases executed by the waves.  Never the timed kernel.
+// triangles tested (both per lane), node and triangle phases executed by the waves.  Never the timed kernel.
 #ifndef PT_BVH_STACK
 #define PT_BVH_STACK 48  // (an overflow array of fewer than 64 dwords is promoted to registers: 126 VGPRs)
 #endif
@@ -1472,7 +1472,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     float ix = 0.0f, iy = 0.0f, iz = 0.0f;
     unsigned budget = 0u;
     unsigned c_nodes = 0, c_leaves = 0;
-    unsigned long long c_steps = 0;
+    unsigned long long c_steps = 0, c_tsteps = 0;
 
     for (;;) {
         if ((unsigned)__popcll(__ballot(trav)) <= (unsigned)PT_BVH_REFILL) {
@@ -1512,7 +1512,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
         const bool any_node = __ballot(want_node) != 0ull;
         if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (!any_node && n_tri != 0u)) {
-            if (TALLY) ++c_steps;
+            if (TALLY) ++c_tsteps;
             if (want_tri) {
                 if (TALLY) ++c_leaves;
                 const unsigned slot = (unsigned)__builtin_ctz(tm & 255u);
@@ -1608,6 +1608,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             atomicAdd(&P.stats[2], n);
             atomicAdd(&P.stats[3], l);
             atomicAdd(&P.stats[4], c_steps);
+            atomicAdd(&P.stats[5], c_tsteps);
         }
     }
     pt_flush_counters(P, lane, n_rays, n_samples);

@@ -21,7 +21,7 @@ PT_INFO_NAME, PT_INFO_BOARD, PT_INFO_VENDOR, PT_INFO_VERSION = range(4)
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64
 PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 8
-PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS = 2, 3, 4
+PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS = 2, 3, 4, 5
 PT_PROF_TRACE, PT_PROF_FOLD = 0, 1
 PT_STREAM_LEGACY = 1  # hipStreamLegacy: how a caller names the legacy default stream to pt_device_set_stream
 

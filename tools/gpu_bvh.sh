@@ -19,6 +19,6 @@ import json
 for l in open("gpurun_out/bvh_${tag}_bench.log"):
     if l.startswith("{"):
         d = json.loads(l); r = d.get("roofline") or {}
-        print("  %-22s %.1f Msamples/s  nodes/ray %.1f  tris/ray %.2f  lane occupancy %.2f  rays/sample %.2f" % ("$lib", d["value"], r.get("nodes_per_ray", 0), r.get("tris_per_ray", 0), r.get("search_lane_occupancy", 0), d["config"]["rays_per_sample"]))
+        print("  %-22s %.1f Msamples/s  nodes/ray %.1f  tris/ray %.2f  lane occupancy node %.2f tri %.2f  rays/sample %.2f" % ("$lib", d["value"], r.get("nodes_per_ray", 0), r.get("tris_per_ray", 0), r.get("node_phase_lane_occupancy", 0), r.get("tri_phase_lane_occupancy", 0), d["config"]["rays_per_sample"]))
 PY
 done
