@@ -189,7 +189,7 @@ def bvh_tallies(dev, lib, shim, tris, mats, W, H, depth):
     dev.setOption(shim.PT_OPT_BVH_TALLY, 1)
     try:
         r = Renderer(dev, tris, mats, W, H, want_stats=True)
-        r.render(2, max_bounces=depth)
+        r.render(16, max_bounces=depth)  # (long enough that the launch's tail, lanes running dry, does not dominate the occupancies)
         st = r.read_stats_raw()
         r.release()
     finally:

@@ -1349,7 +1349,8 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 //     FMA per plane straight from the quantised bytes, the ray's direction signs select the near and far planes of all
 //     eight children at once, the children's slots encode their octant so "slot XOR ray octant" is the front-to-back
 //     order (no sort), and the hits of a node travel as ONE stack entry (base index, hit mask) instead of one per child;
-//   * a lane's state: the current GROUP of node children still to enter (gbase, gm = hits in priority order | imask << 8),
+//   * a lane's state: the current GROUP of node children still to enter (gbase, gm = hits by slot | imask << 8; which
+//     of them comes next is one lookup in a 2 KB table in LDS indexed by the ray's octant and the hits),
 //     the leaf children still to test (tbase, tm = hits by slot | lmask << 8), and a stack of earlier groups
 //     (PT_BVH_LDS_STACK entries in LDS, entry-major: conflict-free; deeper ones in a private array: a radix tree over
 //     64-bit keys has at most 64 levels = 22 levels of eight-child nodes, one entry each);
@@ -1411,17 +1412,6 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
     }
 }
 
-// hits by slot -> hits by priority: bit (slot ^ oct) of the result = bit slot of h (h: 8 bits)
-PTK_DEV unsigned pt_xor_permute8(unsigned h, unsigned oct)
-{
-    const unsigned h1 = ((h & 0x55u) << 1) | ((h >> 1) & 0x55u);
-    h = (oct & 1u) ? h1 : h;
-    const unsigned h2 = ((h & 0x33u) << 2) | ((h >> 2) & 0x33u);
-    h = (oct & 2u) ? h2 : h;
-    const unsigned h4 = ((h & 0x0fu) << 4) | ((h >> 4) & 0x0fu);
-    return (oct & 4u) ? h4 : h;
-}
-
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
@@ -1436,8 +1426,20 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             const int tri = k / PT_LDS_TRI_STRIDE, w = k - tri * PT_LDS_TRI_STRIDE;
             pt_lds_tab[k] = g[tri * 16 + w];
         }
-        __syncthreads();
     }
+    // which child of a group comes next: nxt[oct << 8 | hits] = the slot s among the hits (by slot) with the largest
+    // s ^ oct -- the octant nearest to where the ray comes from (2 KB, after the tails)
+    typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
+    pt_lds_u8* nxt = (pt_lds_u8*)((pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + 2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS +
+                                  (PT_TRACE_THREADS / 64) * (128u + PT_TAIL_LIST));
+    for (unsigned k = threadIdx.x; k < 2048u; k += PT_TRACE_THREADS) {
+        const unsigned o = k >> 8, h = k & 255u;
+        unsigned best = 0u, bp = 0u;
+        for (unsigned sl = 0; sl < 8u; ++sl)
+            if (((h >> sl) & 1u) && ((sl ^ o) >= bp)) { bp = sl ^ o; best = sl; }
+        nxt[k] = (unsigned char)best;
+    }
+    __syncthreads();
     // stack entry e of this lane: stk[2 e * PT_TRACE_THREADS] = base, stk[(2 e + 1) * PT_TRACE_THREADS] = masks
     pt_lds_u32* stk = (pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + threadIdx.x;
     unsigned ovf[2 * (PT_BVH_STACK - PT_BVH_LDS_STACK)];
@@ -1465,7 +1467,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     // the search's state
     float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
     int hidx = -1;
-    unsigned gbase = 0u, gm = 0u;  // the group of node children still to enter: hits by priority (8 bits) | imask << 8
+    unsigned gbase = 0u, gm = 0u;  // the group of node children still to enter: hits by slot (8 bits) | imask << 8
     unsigned tbase = 0u, tm = 0u;  // the leaf children still to test: hits by slot (8 bits) | lmask << 8
     unsigned oct = 0u;             // bit a set: the ray runs towards +a (children on the low side come first)
     int sp = 0;
@@ -1495,9 +1497,9 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.y), -0x1p60f, 0x1p60f);
                     iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.z), -0x1p60f, 0x1p60f);
                     oct = (ix < 0.0f ? 0u : 1u) | (iy < 0.0f ? 0u : 2u) | (iz < 0.0f ? 0u : 4u);
-                    // the root (node 0) as a group of one: slot 0, priority 0 ^ oct
+                    // the root (node 0) as a group of one: slot 0
                     gbase = 0u;
-                    gm = (1u << oct) | (1u << 8);
+                    gm = 1u | (1u << 8);
                     tbase = 0u; tm = 0u;
                     sp = 0;
                     budget = 2u * (unsigned)ntri + 64u;
@@ -1508,10 +1510,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         }
         // ---- one step of the wave ----------------------------------------------------------------
         const bool want_tri = trav && (tm & 255u) != 0u;
-        const bool want_node = trav && !want_tri;  // (such a lane holds a group or a stack entry: otherwise it was retired)
         const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
-        const bool any_node = __ballot(want_node) != 0ull;
-        if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (!any_node && n_tri != 0u)) {
+        if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (n_tri != 0u && __ballot(trav && !want_tri) == 0ull)) {
             if (TALLY) ++c_tsteps;
             if (want_tri) {
                 if (TALLY) ++c_leaves;
@@ -1530,7 +1530,10 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 --budget;
             }
         }
-        if (any_node) {
+        // (a lane that has just tested its last pending triangle enters a node in the same step)
+        if (trav && ((tm & 255u) == 0u) && ((gm & 255u) == 0u) && sp == 0) trav = false;  // nothing left: the closest hit stands
+        const bool want_node = trav && (tm & 255u) == 0u;
+        if (__ballot(want_node) != 0ull) {
             if (TALLY) ++c_steps;
             if (want_node) {
                 if (TALLY) ++c_nodes;
@@ -1540,9 +1543,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     else { gbase = ovf[2 * (sp - PT_BVH_LDS_STACK)]; gm = ovf[2 * (sp - PT_BVH_LDS_STACK) + 1]; }
                 }
                 // the group's next child: highest priority first; its slot, its rank among the node children
-                const unsigned pr = 31u - (unsigned)__builtin_clz((gm & 255u) | 1u);
-                gm &= ~(1u << pr);
-                const unsigned slot = pr ^ oct;
+                const unsigned slot = nxt[(oct << 8) | (gm & 255u)];
+                gm &= ~(1u << slot);
                 const unsigned node = gbase + (unsigned)__popc((gm >> 8) & ((1u << slot) - 1u));
                 unsigned h = 0u, imask = 0u, lmask = 0u, cbase = 0u, lbase = 0u;
                 if (node < n_nodes) {
@@ -1586,7 +1588,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 }
                 if (hn != 0u) {
                     gbase = cbase;
-                    gm = pt_xor_permute8(hn, oct) | (imask << 8);
+                    gm = hn | (imask << 8);
                 }
                 tbase = lbase;
                 tm = ht | (lmask << 8);
@@ -1848,7 +1850,7 @@ size_t ptk_trace_lds_bytes(int ntri)
 size_t ptk_trace_bvh_lds_bytes(void)
 {
     // the big-triangle table + the 256 lanes' stacks + per wave the pass-2 tail (64 x 8 B keys, PT_TAIL_LIST x 4 B pairs)
-    return (size_t)PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE * 4 + (size_t)2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4);
+    return (size_t)PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE * 4 + (size_t)2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS * 4 + (size_t)(PT_TRACE_THREADS / 64) * (64 * 8 + PT_TAIL_LIST * 4) + 2048;
 }
 
 int ptk_trace_bvh_blocks_per_cu(void)
