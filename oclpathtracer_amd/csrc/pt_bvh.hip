@@ -14,10 +14,10 @@
 //
 // Build (Karras 2012): 30-bit Morton code of the box centre | triangle index -> 64-bit keys,
 // hipcub radix sort, one thread per internal node finds its range and split, bottom-up box refit
-// with one atomic flag per internal node.  Only the n-1 internal nodes are stored: a 64-byte record
-// holds BOTH children's boxes and links (a leaf is a link with the top bit set, carrying the
-// triangle index), so one fetch decides which child is nearer (pt_intersect_bvh: near child first,
-// far child on a per-lane stack).
+// with one atomic flag per internal node (fp32 boxes of both children in the binary node).  The binary
+// tree is then collapsed three levels at a time into the eight-child nodes the trace kernel walks
+// (PtBvh8Node, pt_kernels.h: 80 bytes in a 128-byte slot, 8-bit boxes in the node's frame, children
+// stored consecutively, slots assigned by octant): count / scan / assign / emit below.
 #include "pt_kernels.h"
 
 #include <hipcub/hipcub.hpp>
