@@ -188,15 +188,8 @@ __global__ void pt_bvh_hierarchy_kernel(const unsigned long long* __restrict__ k
     if (i == 0) parent[0] = -1;
 }
 
-// leaf c of the hierarchy = the sorted triangles [c << shift, (c + 1) << shift): its key is its first triangle's
-__global__ void pt_bvh_leaf_keys_kernel(const unsigned long long* __restrict__ keys, int nleaves, int shift, unsigned long long* __restrict__ lkeys)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nleaves) lkeys[c] = keys[(size_t)c << shift];
-}
-
-// n = number of leaves; tkeys = the sorted triangle keys (ntri of them)
-__global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ tkeys, int ntri, int shift, int n,
+// one leaf per triangle, in sorted order: n = ntri leaves; tkeys = the sorted triangle keys
+__global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const unsigned long long* __restrict__ tkeys, int n,
                                     const unsigned* __restrict__ bounds, PtBvhNode* nodes,
                                     const int* __restrict__ parent, const int* __restrict__ right_child, int* __restrict__ flags)
 {
@@ -204,8 +197,8 @@ __global__ void pt_bvh_refit_kernel(const PtRawTriangle* __restrict__ raw, const
     if (k >= n) return;
     const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
     float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };  // empty: never entered
-    for (int t = k << shift; t < ((k + 1) << shift) && t < ntri; ++t) {
-        const int tri = (int)(unsigned)tkeys[t];
+    {
+        const int tri = (int)(unsigned)tkeys[k];
         float tlo[3], thi[3];
         if (pt_tri_box(raw[tri], tlo, thi) && !pt_tri_is_big(tlo, thi, bounds))
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tlo[a] - eps); hi[a] = fmaxf(hi[a], thi[a] + eps); }
@@ -449,21 +442,19 @@ size_t ptk_bvh_temp_bytes(int ntri)
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, nullk, nullk, ntri, 0, 62);
     const size_t scan = pt_bvh_scan_bytes(ntri);
     const size_t n = (size_t)ntri;
-    // keys, sorted keys, leaf keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], the fp32 nodes, child counts and
+    // keys, sorted keys, parent[2n-1], right_child[n-1], flags[n-1], bounds[16], the fp32 nodes, child counts and
     // their scan, new indices, cub temp (sort and scan use it in turn)
-    return 24 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + sizeof(PtBvhNode) * n + 16 * n + 4 * n + (cub > scan ? cub : scan) + 2048;
+    return 16 * n + 4 * (2 * n) + 4 * n + 4 * n + 64 + sizeof(PtBvhNode) * n + 16 * n + 4 * n + (cub > scan ? cub : scan) + 2048;
 }
 
 hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes8, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
-    static_assert(PT_BVH_CLUSTER_SHIFT == 0, "one triangle per leaf");
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
     char* p = (char*)temp;
     unsigned long long* keys = (unsigned long long*)p; p += 8 * n;
     unsigned long long* sorted = (unsigned long long*)p; p += 8 * n;
-    unsigned long long* lkeys = (unsigned long long*)p; p += 8 * n;
     unsigned long long* cnt = (unsigned long long*)p; p += 8 * n;
     unsigned long long* base = (unsigned long long*)p; p += 8 * n;
     int* parent = (int*)p; p += 4 * 2 * n;
@@ -488,11 +479,10 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipLaunchKernelGGL(pt_bvh_big_finish_kernel, dim3(1), dim3(1), 0, s, bounds, bigidx, prep, bigtab, nbig_dev);
     hipLaunchKernelGGL(pt_bvh_keys_kernel, grd, blk, 0, s, raw, ntri, bounds, keys);
     if ((e = hipcub::DeviceRadixSort::SortKeys(p, cub, keys, sorted, ntri, 0, 62, s)) != hipSuccess) return e;
-    const int shift = ptk_bvh_shift(ntri), nleaves = ptk_bvh_leaf_count(ntri);  // nleaves >= 2 (ntri >= 2)
+    const int nleaves = ntri;  // one triangle per leaf; nleaves >= 2
     const dim3 lgrd((nleaves + 255) / 256);
-    hipLaunchKernelGGL(pt_bvh_leaf_keys_kernel, lgrd, blk, 0, s, sorted, nleaves, shift, lkeys);
-    hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, lkeys, nleaves, nodes, parent, right_child);
-    hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, ntri, shift, nleaves, bounds, nodes, parent, right_child, flags);
+    hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, sorted, nleaves, nodes, parent, right_child);
+    hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, nleaves, bounds, nodes, parent, right_child, flags);
     hipLaunchKernelGGL(pt_bvh8_count_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, cnt);
     if ((e = hipcub::DeviceScan::ExclusiveSum(p, cub, cnt, base, nleaves - 1, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_bvh8_assign_kernel, lgrd, blk, 0, s, nodes, parent, nleaves, base, newidx);

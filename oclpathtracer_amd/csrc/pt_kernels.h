@@ -67,8 +67,6 @@ static_assert(sizeof(PtBvh8Node) == 128, "bvh node layout");
 // A LEAF of the hierarchy is ONE triangle: a compact 48-byte record, three 16-byte loads.  (Leaves of four
 // consecutive triangles of the Morton order were measured in round 2: the 10^6-triangle soup's leaf boxes grow 9x in
 // cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s.)
-#define PT_BVH_CLUSTER_SHIFT 0
-#define PT_BVH_CLUSTER (1 << PT_BVH_CLUSTER_SHIFT)
 struct PtLeafTri {
     float p1[3], e1[3], e2[3];  // as in PtPrepTriangle
     uint32_t index;             // the triangle's index in the caller's buffer (ties in t go to the lowest)
@@ -102,7 +100,6 @@ struct PtTraceParams {
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
     const PtBvh8Node* bvh;        // accel = BVH: eight-child nodes, root 0, every node's node children consecutive
     const PtLeafTri* ltris;       // accel = BVH: the leaf records, every node's leaf children consecutive
-    int32_t bvh_shift;            //              (unused: one triangle per leaf)
     int32_t bvh_leaves;           //              number of leaves; the hierarchy has at most bvh_leaves - 1 nodes
     const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
     const int32_t* bigidx;        //              their triangle indices, ascending
@@ -147,8 +144,7 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // nodes[ptk_bvh_leaf_count(ntri) - 1] and ltris[ntri] (device memory) receive the hierarchy the trace kernel walks
 hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes, PtLeafTri* ltris,
                          PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
-static inline int ptk_bvh_shift(int ntri) { return ntri >= 4 * PT_BVH_CLUSTER ? PT_BVH_CLUSTER_SHIFT : 0; }
-static inline int ptk_bvh_leaf_count(int ntri) { const int sh = ptk_bvh_shift(ntri); return (ntri + (1 << sh) - 1) >> sh; }
+static inline int ptk_bvh_leaf_count(int ntri) { return ntri; }  // one triangle per leaf
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);

@@ -906,7 +906,6 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
         tp.ltris = d->ltris;
-        tp.bvh_shift = ptk_bvh_shift(rp.num_triangles);
         tp.bvh_leaves = ptk_bvh_leaf_count(rp.num_triangles);
         tp.bigtab = d->bigtab;
         tp.bigidx = d->bigidx;
