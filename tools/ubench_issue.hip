@@ -149,6 +149,40 @@ BODY_BEGIN(47) A8(I47); BODY_END
 #define I48(k) "v_ffbh_u32_e32 %" #k ", %" #k "\n\t"
 BODY_BEGIN(48) A8(I48); BODY_END
 
+// round 2 additions (the LBVH node step's instruction mix)
+#define I60(k) "v_fma_mix_f32 %" #k ", %" #k ", %10, %11 op_sel_hi:[1,0,0]\n\t"
+BODY_BEGIN(60) A8(I60); BODY_END
+#define I61(k) "v_fma_mix_f32 %" #k ", %" #k ", %10, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+BODY_BEGIN(61) A8(I61); BODY_END
+#define I62(k) "v_cvt_f32_ubyte0_e32 %" #k ", %" #k "\n\t"
+BODY_BEGIN(62) A8(I62); BODY_END
+#define I63(k) "v_cvt_f32_ubyte2_e32 %" #k ", %" #k "\n\t"
+BODY_BEGIN(63) A8(I63); BODY_END
+#define I64(k) "v_max3_f32 %" #k ", %" #k ", %10, %11\n\t"
+BODY_BEGIN(64) A8(I64); BODY_END
+#define I65(k) "v_min3_f32 %" #k ", %" #k ", %10, %11\n\t"
+BODY_BEGIN(65) A8(I65); BODY_END
+#define I66(k) "v_perm_b32 %" #k ", %" #k ", %10, %9\n\t"
+BODY_BEGIN(66) A8(I66); BODY_END
+#define I67(k) "v_bfe_u32 %" #k ", %" #k ", 8, 8\n\t"
+BODY_BEGIN(67) A8(I67); BODY_END
+#define I68(k) "v_and_or_b32 %" #k ", %" #k ", %9, %8\n\t"
+BODY_BEGIN(68) A8(I68); BODY_END
+#define I69(k) "v_bcnt_u32_b32 %" #k ", %" #k ", %9\n\t"
+BODY_BEGIN(69) A8(I69); BODY_END
+#define I70(k) "v_cvt_f32_f16_e32 %" #k ", %" #k "\n\t"
+BODY_BEGIN(70) A8(I70); BODY_END
+#define I71(k) "v_cvt_f32_ubyte0_e32 %" #k ", %" #k "\n\tv_fma_f32 %" #k ", %" #k ", %10, %11\n\t"
+BODY_BEGIN(71) A8(I71); BODY_END
+#define I72(k) "v_min_f32_e32 %" #k ", %" #k ", %10\n\t"
+BODY_BEGIN(72) A8(I72); BODY_END
+#define I73(k) "v_cmp_le_f32_e64 s[20:21], %10, %" #k "\n\tv_addc_co_u32_e64 %8, s[24:25], %8, %8, s[20:21]\n\t"
+BODY_BEGIN(73) A8(I73); BODY_END
+#define I74(k) "v_or_b32_e32 %" #k ", %" #k ", %9\n\t"
+BODY_BEGIN(74) A8(I74); BODY_END
+#define I75(k) "v_lshrrev_b32_e32 %" #k ", 8, %" #k "\n\t"
+BODY_BEGIN(75) A8(I75); BODY_END
+
 // packed: 4 register pairs p0..p3 (from d0..d3 reinterpretation), one instruction = 2 fp32 results
 typedef float pt_f2 __attribute__((ext_vector_type(2)));
 #define PK_BODY(ID, INS) BODY_BEGIN(ID) \
@@ -210,6 +244,28 @@ int main()
     g_clock_hz = p.clockRate * 1e3;
     printf("device: %s (%s), %d CUs, clock %d kHz; one group = the listed instructions, 8 independent groups in flight per wave\n",
            p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    if (getenv("UBENCH_R02")) {  // only the round-2 additions
+        for (int w : {5, 8}) {
+            run<0>("v_fma_f32 v,v,v", 1, w);
+            run<60>("v_fma_mix_f32 v(f16 lo),v,v", 1, w);
+            run<61>("v_fma_mix_f32 v(f16 hi),v,v", 1, w);
+            run<62>("v_cvt_f32_ubyte0", 1, w);
+            run<63>("v_cvt_f32_ubyte2", 1, w);
+            run<71>("v_cvt_f32_ubyte0 + v_fma_f32 v,v,v", 2, w);
+            run<70>("v_cvt_f32_f16", 1, w);
+            run<64>("v_max3_f32", 1, w);
+            run<65>("v_min3_f32", 1, w);
+            run<72>("v_min_f32", 1, w);
+            run<73>("v_cmp_le_f32_e64 + v_addc_co_u32_e64", 2, w);
+            run<66>("v_perm_b32", 1, w);
+            run<67>("v_bfe_u32", 1, w);
+            run<68>("v_and_or_b32", 1, w);
+            run<74>("v_or_b32", 1, w);
+            run<75>("v_lshrrev_b32", 1, w);
+            run<69>("v_bcnt_u32_b32", 1, w);
+        }
+        return 0;
+    }
     for (int w : {7, 8}) {
         run<0>("v_fma_f32 v,v,v", 1, w);
         run<18>("v_fma_f32 dependent chain", 1, w);
