@@ -409,6 +409,67 @@ def test_bvh_matches_oracle(device, oracle, kind, ntri):
     assert gst["rays"] == st["rays"]
 
 
+def _bvh_edge_scene(kind):
+    """Scenes that steer the LBVH builder into its corner cases (csrc/pt_bvh.hip: radix tree, eight-child collapse, big
+    triangles outside the tree)."""
+    from oclpathtracer_amd import scene
+
+    box, mats = scene.load_model()
+    rng = np.random.default_rng(99)
+
+    def small(n, centres, size=0.05):
+        t = np.zeros(n, scene.TRIANGLE_DTYPE)
+        c = centres.astype(np.float32)
+        t["p1"][:, :3] = c
+        t["p2"][:, :3] = c + rng.uniform(-size, size, (n, 3)).astype(np.float32)
+        t["p3"][:, :3] = c + rng.uniform(-size, size, (n, 3)).astype(np.float32)
+        t["id"] = rng.integers(0, len(mats), n)
+        return t
+
+    lo, span = np.array([-2.5, 0.2, -5.2]), np.array([5.0, 5.0, 5.0])
+    if kind == "two":            # the smallest hierarchy: one node, two leaves
+        return box[20:22].copy(), mats
+    if kind == "three":
+        return box[20:23].copy(), mats
+    if kind == "nine":           # one more leaf than a node holds
+        return small(9, lo + span * rng.random((9, 3)), 0.8), mats
+    if kind == "duplicates":     # 300 copies of one triangle (equal Morton codes: the tree splits on the index bits) in the box
+        t = small(1, (lo + span * 0.5)[None, :], 0.6)
+        return np.concatenate([box, np.repeat(t, 300)]), mats
+    if kind == "clustered":      # centres at 1 - 2^-k along the diagonal: every radix split peels one leaf off, a deep chain
+        k = np.arange(1, 25)
+        c = lo[None, :] + span[None, :] * (1.0 - 2.0 ** -k)[:, None]
+        return np.concatenate([box, small(24, c, 0.02), small(400, lo + span * rng.random((400, 3)))]), mats
+    if kind == "many_big":       # more big triangles than the brute-force table holds (64): they all stay in the tree
+        return np.concatenate([box, small(90, lo + span * rng.random((90, 3)), 2.5), small(500, lo + span * rng.random((500, 3)))]), mats
+    if kind == "flat":           # every centre in one plane: one Morton axis carries no information
+        c = lo + span * rng.random((700, 3))
+        c[:, 1] = 2.0
+        return np.concatenate([box, small(700, c)]), mats
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["two", "three", "nine", "duplicates", "clustered", "many_big", "flat"])
+def test_bvh_builder_corner_cases_match_oracle(device, oracle, kind):
+    """PT_OPT_ACCEL = 2 on scenes chosen for the builder, bit for bit against the brute-force oracle."""
+    from oclpathtracer_amd import shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = _bvh_edge_scene(kind)
+    W, H, frames = 48, 40, 3
+    want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
+    device.setOption(shim.PT_OPT_ACCEL, 2)
+    r = Renderer(device, tris, mats, W, H, want_stats=True)
+    try:
+        r.render(frames)
+        got, gst = r.read(), r.read_stats()
+    finally:
+        r.release()
+        device.setOption(shim.PT_OPT_ACCEL, 0)
+    assert_fb_equal(got, want, "bvh corner case %s" % kind)
+    assert gst["rays"] == st["rays"]
+
+
 def test_bvh_matches_gpu_brute_force_200k_triangles(device):
     """A soup too large for the CPU oracle: the LBVH against the brute-force kernel on the same GPU."""
     from oclpathtracer_amd import scene, shim

@@ -9,7 +9,7 @@ for lib in "$@"; do
   tag=${lib%.so}
   if [ $first -eq 1 ]; then
     first=0
-    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "${BVH_TESTS:-bvh or soup or lbvh or random_quad or ties or golden}" > gpurun_out/bvh_${tag}_pytest.log 2>&1
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "${BVH_TESTS:-bvh or soup or lbvh or random_quad or ties or golden or corner}" > gpurun_out/bvh_${tag}_pytest.log 2>&1
     rc=$?; echo "$lib pytest rc=$rc $(tail -1 gpurun_out/bvh_${tag}_pytest.log)"
     [ $rc -ne 0 ] && { tail -30 gpurun_out/bvh_${tag}_pytest.log; exit $rc; }
   fi
