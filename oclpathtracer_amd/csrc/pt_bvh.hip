@@ -383,7 +383,12 @@ __global__ void pt_bvh8_emit_kernel(const PtBvhNode* __restrict__ wide, const in
                     PtLeafTri r;
                     for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
                     r.index = tri;
-                    r.pad[0] = r.pad[1] = 0.0f;
+                    for (unsigned z = 0; z < sizeof r.pad / sizeof r.pad[0]; ++z) r.pad[z] = 0.0f;
+                    if (rank == 0u) {  // the first leaf's record also rides in the node's own line (the trace kernel reads it there)
+                        static_assert(sizeof o.pad >= 48, "room for one leaf record");
+                        const uint32_t* w = reinterpret_cast<const uint32_t*>(&r);
+                        for (int z = 0; z < 12; ++z) o.pad[z] = w[z];
+                    }
                     ltris[o.tri_base + rank++] = r;
                 }
     }

@@ -60,19 +60,22 @@ struct alignas(128) PtBvh8Node {
     uint32_t pad0;
     uint8_t qlo[3][8];    // [axis][slot]
     uint8_t qhi[3][8];
-    uint32_t pad[12];
+    uint32_t pad[12];     // a copy of the first leaf child's record (PtLeafTri's first 48 bytes), zero without leaf children
 };
 static_assert(sizeof(PtBvh8Node) == 128, "bvh node layout");
 
 // A LEAF of the hierarchy is ONE triangle: a compact 48-byte record, three 16-byte loads.  (Leaves of four
 // consecutive triangles of the Morton order were measured in round 2: the 10^6-triangle soup's leaf boxes grow 9x in
 // cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s.)
-struct PtLeafTri {
+#ifndef PT_LEAF_STRIDE
+#define PT_LEAF_STRIDE 64  // (48 bytes of data: a 48-byte stride lets a quarter of the records straddle two 128-byte lines: 202 against 209 Msamples/s)
+#endif
+struct alignas(PT_LEAF_STRIDE == 64 ? 64 : 16) PtLeafTri {
     float p1[3], e1[3], e2[3];  // as in PtPrepTriangle
     uint32_t index;             // the triangle's index in the caller's buffer (ties in t go to the lowest)
-    float pad[2];
+    float pad[PT_LEAF_STRIDE / 4 - 10];
 };
-static_assert(sizeof(PtLeafTri) == 48, "leaf record layout");
+static_assert(sizeof(PtLeafTri) == PT_LEAF_STRIDE, "leaf record layout");
 
 #define PT_TRACE_BATCH 256u    // largest number of samples per work-queue grab of a wave (PtTraceParams::batch)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)

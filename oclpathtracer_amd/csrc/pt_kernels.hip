@@ -1469,6 +1469,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     int hidx = -1;
     unsigned gbase = 0u, gm = 0u;  // the group of node children still to enter: hits by slot (8 bits) | imask << 8
     unsigned tbase = 0u, tm = 0u;  // the leaf children still to test: hits by slot (8 bits) | lmask << 8
+    unsigned tnode = 0u;           // ... and the node they belong to
     unsigned oct = 0u;             // bit a set: the ray runs towards +a (children on the low side come first)
     int sp = 0;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f;
@@ -1517,9 +1518,12 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (TALLY) ++c_leaves;
                 const unsigned slot = (unsigned)__builtin_ctz(tm & 255u);
                 tm &= tm - 1u;  // (the lowest set bit is a hit bit: the hits are the low byte and not empty)
-                const unsigned idx = tbase + (unsigned)__popc((tm >> 8) & ((1u << slot) - 1u));
+                const unsigned rank = (unsigned)__popc((tm >> 8) & ((1u << slot) - 1u));
+                const unsigned idx = tbase + rank;
                 if (idx < (unsigned)ntri) {
-                    const float4* qp = reinterpret_cast<const float4*>(P.ltris + idx);
+                    // a node's first leaf has a copy of its record in the node's own line (bytes 80..127): no second request
+                    const float4* qp = rank == 0u ? reinterpret_cast<const float4*>(P.bvh + tnode) + 5
+                                                  : reinterpret_cast<const float4*>(P.ltris + idx);
                     const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
                     PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
                     r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
@@ -1591,6 +1595,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     gm = hn | (imask << 8);
                 }
                 tbase = lbase;
+                tnode = node;
                 tm = ht | (lmask << 8);
                 --budget;
             }
