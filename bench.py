@@ -43,9 +43,9 @@ F_GEN, F_ACC = 60.0, 36.0
 F_TRI = {"cull": 20.0, "rej_u": 30.0, "rej_v": 46.0, "reach_t": 52.0}
 F_ACCEPT, F_SHADE_DIFFUSE, F_SHADE_SPECULAR = 33.0, 120.0, 160.0
 BYTES_PER_SAMPLE = 32.0         # 16 B read + 16 B write of one float4 pixel (GenerateColors.cl:314-321)
-# LBVH search (configs[4]): per four-child node entered, four slab tests (6 sub, 6 mul, 12 min/max, 3 compares = 27
-# flop each) + ordering; per triangle tested the reference's full test (52, reach_t) -- DESIGN.md S4
-F_BVH_NODE, F_BVH_TRI = 161.0, 52.0  # an eight-child node: 8 x (6 FMA + 6 min/max + 1 compare) + 9 for the node's frame
+# LBVH search (configs[4]): per eight-child node entered, eight slab tests (6 FMA = 12 flop, 6 min/max, 1 compare = 19
+# flop each) + 9 for the node's frame; per triangle tested the reference's full test (52, reach_t) -- DESIGN.md S4
+F_BVH_NODE, F_BVH_TRI = 161.0, 52.0
 B_BVH_NODE, B_BVH_TRI = 80.0, 48.0   # the 80 bytes read of a node's 128-byte slot per node entered, one 48-byte leaf record per triangle tested
 
 
