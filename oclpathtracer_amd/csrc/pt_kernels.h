@@ -39,8 +39,8 @@ static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 // records and at 86 G/s for aligned 128-byte records; the search is bound by its line requests and by VALU issue in
 // about equal parts, so a node holds as many children as a line allows and costs as few instructions as possible --
 // after Ylitie, Karras, Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017):
-//   * the binary radix tree is collapsed three levels at a time: every binary node at a depth that is a multiple of
-//     three becomes a node whose children are its descendants three levels down, or shallower ones that are leaves;
+//   * which binary nodes of the radix tree become nodes here, and which of their descendants their (at most eight)
+//     children are, is chosen by dynamic programming over surface-area costs (pt_bvh.hip);
 //   * children that are nodes are stored CONSECUTIVELY (child_base + rank among the node children, in slot order),
 //     children that are leaves have their 48-byte records consecutively in the leaf array (tri_base + rank): no links;
 //   * a child sits in the slot whose three bits say on which side of the node's centre it lies (x = bit 0, y = bit 1,

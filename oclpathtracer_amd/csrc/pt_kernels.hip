@@ -1344,8 +1344,9 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 // together, and as soon as no more than PT_BVH_REFILL of them are still traversing, the finished lanes are shaded,
 // dead ones take new samples, and all of them start their next search while the stragglers simply keep theirs.
 //   * the hierarchy: eight-child nodes of 80 bytes in 128-byte slots (PtBvh8Node, pt_kernels.h; built by pt_bvh.hip),
-//     one line request per node.  The search is bound by line requests and by VALU issue in about equal parts
-//     (profiles/r02/ubench_gather.txt), so the node step is built for few instructions: entry / exit distances are one
+//     one line request per node.  The search runs at the rate its L2 misses are served at, with the vector ALUs ~90 %
+//     busy beside it (profiles/r02/pmc_soup_lbvh_cw8.txt), so a node is one line and the node step is built for few
+//     instructions: entry / exit distances are one
 //     FMA per plane straight from the quantised bytes, the ray's direction signs select the near and far planes of all
 //     eight children at once, the children's slots encode their octant so "slot XOR ray octant" is the front-to-back
 //     order (no sort), and the hits of a node travel as ONE stack entry (base index, hit mask) instead of one per child;
