@@ -230,9 +230,9 @@ def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):
              "measured_fetch_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
              "note": "algorithmic = 80 B per eight-child node entered + 48 B per triangle tested + 12 B radiance per sample; the upper "
                      "tree levels are served by L1 / L2, so the algorithmic rate exceeds what crosses the L2's miss path "
-                     "(`traffic`, measured: FETCH_SIZE x 2).  PMC (profiles/r02/pmc_soup_lbvh_cw8.txt): 32.7 L2 misses per ray = 56 G line "
-                     "requests/s, the same rate in three successive builds (150, 202, 219 Msamples/s): the launch runs at the rate its "
-                     "misses are served at (7.2 TB/s if each moves its 128-byte line); the vector ALUs issue ~90 % of the time beside it", **tally},
+                     "(`traffic`, measured: FETCH_SIZE x 2).  PMC (profiles/r02/pmc_soup_lbvh_cw8.txt): 29.7 L2 misses per ray = 54 G line "
+                     "requests/s, the same rate (54-56 G/s) in four successive builds (150, 202, 219, 233 Msamples/s): the launch runs at the rate its "
+                     "misses are served at (6.9 TB/s if each moves its 128-byte line); the vector ALUs issue ~94 % of the time beside it", **tally},
             {"bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
              "traffic": None, "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": flops,
              "flops_basis": "per ray: %.1f nodes entered x %.0f + %.2f triangles tested x %.0f + %.0f shading (tallied render, PT_OPT_BVH_TALLY)"
