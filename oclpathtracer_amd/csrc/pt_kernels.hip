@@ -1413,6 +1413,139 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
     }
 }
 
+// a lane's search state (pt_bvh_step): the closest hit so far, the group of node children still to enter (gbase, gm = hits by
+// slot | imask << 8), the leaf children still to test (tbase, tm = hits by slot | lmask << 8, of node tnode), the stack depth
+struct PtBvhLane {
+    float tmax, hu, hv;
+    int hidx;
+    unsigned gbase, gm, tbase, tm, tnode;
+    unsigned oct;  // bit a set: the ray runs towards +a (children on the low side come first)
+    int sp;
+    float ix, iy, iz;
+    unsigned budget;
+};
+
+// the search of a new ray starts at the root (tmax, hu, hv, hidx are the caller's: the big triangles were searched first)
+PTK_DEV void pt_bvh_lane_start(PtBvhLane& L, const f3& d, int ntri)
+{
+    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the boxes' margin), clamped
+    // to +-2^60: a zero component keeps its sign and every product stays finite
+    L.ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -0x1p60f, 0x1p60f);
+    L.iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -0x1p60f, 0x1p60f);
+    L.iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -0x1p60f, 0x1p60f);
+    L.oct = (L.ix < 0.0f ? 0u : 1u) | (L.iy < 0.0f ? 0u : 2u) | (L.iz < 0.0f ? 0u : 4u);
+    L.gbase = 0u;  // the root (node 0) as a group of one: slot 0
+    L.gm = 1u | (1u << 8);
+    L.tbase = 0u; L.tm = 0u; L.tnode = 0u;
+    L.sp = 0;
+    L.budget = 2u * (unsigned)ntri + 64u;
+}
+
+typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
+
+// one step of the wave: a triangle phase when enough lanes hold pending leaves, then a node phase (see above).  stk: this
+// lane's stack in LDS, ovf: its overflow in scratch, nxt: the 2 KB child-order table
+template <bool DET_BOUNDED, bool TALLY>
+PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const f3& o, const f3& d, pt_lds_u32* stk, unsigned* ovf,
+                         const pt_lds_u8* nxt, unsigned n_nodes, int ntri, unsigned& c_nodes, unsigned& c_leaves,
+                         unsigned long long& c_steps, unsigned long long& c_tsteps)
+{
+    // ---- one step of the wave ----------------------------------------------------------------
+    const bool want_tri = trav && (L.tm & 255u) != 0u;
+    const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
+    if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (n_tri != 0u && __ballot(trav && !want_tri) == 0ull)) {
+        if (TALLY) ++c_tsteps;
+        if (want_tri) {
+            if (TALLY) ++c_leaves;
+            const unsigned slot = (unsigned)__builtin_ctz(L.tm & 255u);
+            L.tm &= L.tm - 1u;  // (the lowest set bit is a hit bit: the hits are the low byte and not empty)
+            const unsigned rank = (unsigned)__popc((L.tm >> 8) & ((1u << slot) - 1u));
+            const unsigned idx = L.tbase + rank;
+            if (idx < (unsigned)ntri) {
+                // a node's first leaf has a copy of its record in the node's own line (bytes 80..127): no second request
+                const float4* qp = rank == 0u ? reinterpret_cast<const float4*>(P.bvh + L.tnode) + 5
+                                              : reinterpret_cast<const float4*>(P.ltris + idx);
+                const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
+                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
+                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), o, d, L.tmax, L.hu, L.hv, L.hidx);
+            }
+            --L.budget;
+        }
+    }
+    // (a lane that has just tested its last pending triangle enters a node in the same step)
+    if (trav && ((L.tm & 255u) == 0u) && ((L.gm & 255u) == 0u) && L.sp == 0) trav = false;  // nothing left: the closest hit stands
+    const bool want_node = trav && (L.tm & 255u) == 0u;
+    if (__ballot(want_node) != 0ull) {
+        if (TALLY) ++c_steps;
+        if (want_node) {
+            if (TALLY) ++c_nodes;
+            if ((L.gm & 255u) == 0u) {  // (then L.sp > 0)
+                L.sp = L.sp > 0 ? L.sp - 1 : 0;
+                if (L.sp < PT_BVH_LDS_STACK) { L.gbase = stk[(2 * L.sp) * PT_TRACE_THREADS]; L.gm = stk[(2 * L.sp + 1) * PT_TRACE_THREADS]; }
+                else { L.gbase = ovf[2 * (L.sp - PT_BVH_LDS_STACK)]; L.gm = ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1]; }
+            }
+            // the group's next child: highest priority first; its slot, its rank among the node children
+            const unsigned slot = nxt[(L.oct << 8) | (L.gm & 255u)];
+            L.gm &= ~(1u << slot);
+            const unsigned node = L.gbase + (unsigned)__popc((L.gm >> 8) & ((1u << slot) - 1u));
+            unsigned h = 0u, imask = 0u, lmask = 0u, cbase = 0u, lbase = 0u;
+            if (node < n_nodes) {
+                const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
+                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
+                const unsigned meta = w0.w;
+                const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
+                            sz = __uint_as_float(((meta >> 16) & 255u) << 23);
+                imask = meta >> 24;
+                cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
+                // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
+                // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
+                // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
+                const float kx = sx * L.ix, ky = sy * L.iy, kz = sz * L.iz;
+                const float cx = (__uint_as_float(w0.x) - o.x) * L.ix, cy = (__uint_as_float(w0.y) - o.y) * L.iy,
+                            cz = (__uint_as_float(w0.z) - o.z) * L.iz;
+                // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
+                // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
+                const bool px = (L.oct & 1u) != 0u, py = (L.oct & 2u) != 0u, pz = (L.oct & 4u) != 0u;
+                const unsigned nx0 = px ? w2.x : w3.z, nx1 = px ? w2.y : w3.w, fx0 = px ? w3.z : w2.x, fx1 = px ? w3.w : w2.y;
+                const unsigned ny0 = py ? w2.z : w4.x, ny1 = py ? w2.w : w4.y, fy0 = py ? w4.x : w2.z, fy1 = py ? w4.y : w2.w;
+                const unsigned nz0 = pz ? w3.x : w4.z, nz1 = pz ? w3.y : w4.w, fz0 = pz ? w4.z : w3.x, fz1 = pz ? w4.w : w3.y;
+#define PT_B8(lo_, hi_, k) (float)((((k) < 4 ? (lo_) : (hi_)) >> (8 * ((k) & 3))) & 255u)
+#pragma unroll
+                for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
+                    const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
+                    const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
+                    const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+                    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, L.tmax));
+                    h = pt_push_flag(h, PT_LANES(tn <= tf));
+                }
+#undef PT_B8
+            }
+            const unsigned hn = h & imask, ht = h & lmask;
+            // the rest of the old group goes on the stack, the children just hit become the current group
+            if ((L.gm & 255u) != 0u && hn != 0u) {
+                if (L.sp < PT_BVH_LDS_STACK) { stk[(2 * L.sp) * PT_TRACE_THREADS] = L.gbase; stk[(2 * L.sp + 1) * PT_TRACE_THREADS] = L.gm; }
+                else if (L.sp < PT_BVH_STACK) { ovf[2 * (L.sp - PT_BVH_LDS_STACK)] = L.gbase; ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1] = L.gm; }
+                L.sp = L.sp < PT_BVH_STACK ? L.sp + 1 : L.sp;
+            }
+            if (hn != 0u) {
+                L.gbase = cbase;
+                L.gm = hn | (imask << 8);
+            }
+            L.tbase = lbase;
+            L.tnode = node;
+            L.tm = ht | (lmask << 8);
+            --L.budget;
+        }
+    }
+    // a lane with nothing left to enter or test has its closest hit
+    if (trav && ((L.tm & 255u) == 0u) && ((L.gm & 255u) == 0u) && L.sp == 0) trav = false;
+    if (trav && (int)L.budget <= 0) trav = false;
+}
+
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
@@ -1430,7 +1563,6 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     }
     // which child of a group comes next: nxt[oct << 8 | hits] = the slot s among the hits (by slot) with the largest
     // s ^ oct -- the octant nearest to where the ray comes from (2 KB, after the tails)
-    typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
     pt_lds_u8* nxt = (pt_lds_u8*)((pt_lds_u32*)pt_lds_tab + PT_BVH_BIG_MAX * PT_LDS_TRI_STRIDE + 2 * PT_BVH_LDS_STACK * PT_TRACE_THREADS +
                                   (PT_TRACE_THREADS / 64) * (128u + PT_TAIL_LIST));
     for (unsigned k = threadIdx.x; k < 2048u; k += PT_TRACE_THREADS) {
@@ -1465,145 +1597,34 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     s.mask = mk3(1.0f, 1.0f, 1.0f); s.L = mk3(0.0f, 0.0f, 0.0f);
     s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
     unsigned n_rays = 0, n_samples = 0;
-    // the search's state
-    float tmax = 1e20f, hu = 0.0f, hv = 0.0f;
-    int hidx = -1;
-    unsigned gbase = 0u, gm = 0u;  // the group of node children still to enter: hits by slot (8 bits) | imask << 8
-    unsigned tbase = 0u, tm = 0u;  // the leaf children still to test: hits by slot (8 bits) | lmask << 8
-    unsigned tnode = 0u;           // ... and the node they belong to
-    unsigned oct = 0u;             // bit a set: the ray runs towards +a (children on the low side come first)
-    int sp = 0;
-    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
-    unsigned budget = 0u;
+    PtBvhLane L;  // the search's state
+    L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1;
+    L.gbase = L.gm = L.tbase = L.tm = L.tnode = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
     unsigned c_nodes = 0, c_leaves = 0;
     unsigned long long c_steps = 0, c_tsteps = 0;
 
     for (;;) {
         if ((unsigned)__popcll(__ballot(trav)) <= (unsigned)PT_BVH_REFILL) {
-            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx, n_rays, n_samples);
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
             const bool start = alive && !trav;
             if (__ballot(start) != 0ull) {
-                if (start) { tmax = 1e20f; hu = 0.0f; hv = 0.0f; hidx = -1; }
+                if (start) { L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1; }
                 if (P.nbig > 0) {
                     // the triangles outside the hierarchy, in ascending index order; hp = position in their table
                     int hp = -1;
-                    pt_intersect_two_pass<DET_BOUNDED, 1, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, tmax, hu, hv, hp, 0.0f, 0.0f,
+                    pt_intersect_two_pass<DET_BOUNDED, 1, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, L.tmax, L.hu, L.hv, hp, 0.0f, 0.0f,
                                                                  nullptr, 0.0f, 0.0f, tl, lane);
-                    if (start && hp >= 0) hidx = P.bigidx[hp];
+                    if (start && hp >= 0) L.hidx = P.bigidx[hp];
                 }
                 if (start) {
-                    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the boxes'
-                    // margin), clamped to +-2^60: a zero component keeps its sign and every product stays finite
-                    ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.x), -0x1p60f, 0x1p60f);
-                    iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.y), -0x1p60f, 0x1p60f);
-                    iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(s.d.z), -0x1p60f, 0x1p60f);
-                    oct = (ix < 0.0f ? 0u : 1u) | (iy < 0.0f ? 0u : 2u) | (iz < 0.0f ? 0u : 4u);
-                    // the root (node 0) as a group of one: slot 0
-                    gbase = 0u;
-                    gm = 1u | (1u << 8);
-                    tbase = 0u; tm = 0u;
-                    sp = 0;
-                    budget = 2u * (unsigned)ntri + 64u;
+                    pt_bvh_lane_start(L, s.d, ntri);
                     trav = true;
                 }
             }
             if (__ballot(alive) == 0ull) break;
         }
-        // ---- one step of the wave ----------------------------------------------------------------
-        const bool want_tri = trav && (tm & 255u) != 0u;
-        const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
-        if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (n_tri != 0u && __ballot(trav && !want_tri) == 0ull)) {
-            if (TALLY) ++c_tsteps;
-            if (want_tri) {
-                if (TALLY) ++c_leaves;
-                const unsigned slot = (unsigned)__builtin_ctz(tm & 255u);
-                tm &= tm - 1u;  // (the lowest set bit is a hit bit: the hits are the low byte and not empty)
-                const unsigned rank = (unsigned)__popc((tm >> 8) & ((1u << slot) - 1u));
-                const unsigned idx = tbase + rank;
-                if (idx < (unsigned)ntri) {
-                    // a node's first leaf has a copy of its record in the node's own line (bytes 80..127): no second request
-                    const float4* qp = rank == 0u ? reinterpret_cast<const float4*>(P.bvh + tnode) + 5
-                                                  : reinterpret_cast<const float4*>(P.ltris + idx);
-                    const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
-                    PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
-                    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
-                    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
-                    r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
-                    pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), s.o, s.d, tmax, hu, hv, hidx);
-                }
-                --budget;
-            }
-        }
-        // (a lane that has just tested its last pending triangle enters a node in the same step)
-        if (trav && ((tm & 255u) == 0u) && ((gm & 255u) == 0u) && sp == 0) trav = false;  // nothing left: the closest hit stands
-        const bool want_node = trav && (tm & 255u) == 0u;
-        if (__ballot(want_node) != 0ull) {
-            if (TALLY) ++c_steps;
-            if (want_node) {
-                if (TALLY) ++c_nodes;
-                if ((gm & 255u) == 0u) {  // (then sp > 0)
-                    sp = sp > 0 ? sp - 1 : 0;
-                    if (sp < PT_BVH_LDS_STACK) { gbase = stk[(2 * sp) * PT_TRACE_THREADS]; gm = stk[(2 * sp + 1) * PT_TRACE_THREADS]; }
-                    else { gbase = ovf[2 * (sp - PT_BVH_LDS_STACK)]; gm = ovf[2 * (sp - PT_BVH_LDS_STACK) + 1]; }
-                }
-                // the group's next child: highest priority first; its slot, its rank among the node children
-                const unsigned slot = nxt[(oct << 8) | (gm & 255u)];
-                gm &= ~(1u << slot);
-                const unsigned node = gbase + (unsigned)__popc((gm >> 8) & ((1u << slot) - 1u));
-                unsigned h = 0u, imask = 0u, lmask = 0u, cbase = 0u, lbase = 0u;
-                if (node < n_nodes) {
-                    const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
-                    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
-                    const unsigned meta = w0.w;
-                    const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
-                                sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-                    imask = meta >> 24;
-                    cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
-                    // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
-                    // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
-                    // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
-                    const float kx = sx * ix, ky = sy * iy, kz = sz * iz;
-                    const float cx = (__uint_as_float(w0.x) - s.o.x) * ix, cy = (__uint_as_float(w0.y) - s.o.y) * iy,
-                                cz = (__uint_as_float(w0.z) - s.o.z) * iz;
-                    // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
-                    // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
-                    const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
-                    const unsigned nx0 = px ? w2.x : w3.z, nx1 = px ? w2.y : w3.w, fx0 = px ? w3.z : w2.x, fx1 = px ? w3.w : w2.y;
-                    const unsigned ny0 = py ? w2.z : w4.x, ny1 = py ? w2.w : w4.y, fy0 = py ? w4.x : w2.z, fy1 = py ? w4.y : w2.w;
-                    const unsigned nz0 = pz ? w3.x : w4.z, nz1 = pz ? w3.y : w4.w, fz0 = pz ? w4.z : w3.x, fz1 = pz ? w4.w : w3.y;
-#define PT_B8(lo_, hi_, k) (float)((((k) < 4 ? (lo_) : (hi_)) >> (8 * ((k) & 3))) & 255u)
-#pragma unroll
-                    for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
-                        const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
-                        const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
-                        const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
-                        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-                        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tmax));
-                        h = pt_push_flag(h, PT_LANES(tn <= tf));
-                    }
-#undef PT_B8
-                }
-                const unsigned hn = h & imask, ht = h & lmask;
-                // the rest of the old group goes on the stack, the children just hit become the current group
-                if ((gm & 255u) != 0u && hn != 0u) {
-                    if (sp < PT_BVH_LDS_STACK) { stk[(2 * sp) * PT_TRACE_THREADS] = gbase; stk[(2 * sp + 1) * PT_TRACE_THREADS] = gm; }
-                    else if (sp < PT_BVH_STACK) { ovf[2 * (sp - PT_BVH_LDS_STACK)] = gbase; ovf[2 * (sp - PT_BVH_LDS_STACK) + 1] = gm; }
-                    sp = sp < PT_BVH_STACK ? sp + 1 : sp;
-                }
-                if (hn != 0u) {
-                    gbase = cbase;
-                    gm = hn | (imask << 8);
-                }
-                tbase = lbase;
-                tnode = node;
-                tm = ht | (lmask << 8);
-                --budget;
-            }
-        }
-        // a lane with nothing left to enter or test has its closest hit
-        if (trav && ((tm & 255u) == 0u) && ((gm & 255u) == 0u) && sp == 0) trav = false;
-        if (trav && (int)budget <= 0) trav = false;
+        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, n_nodes, ntri, c_nodes, c_leaves, c_steps, c_tsteps);
     }
 
     if (TALLY && P.stats) {
