@@ -278,27 +278,34 @@ def main():
     lib = shim.load()
     dev.setOption(shim.PT_OPT_QUAD_FILTER, args.quad_filter)
     dev.setOption(shim.PT_OPT_ACCEL, args.accel)
-    img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True)
+    # N > 1: two framebuffers per rank, so that the RCCL gather of one step runs beside the next step's render
+    # (StripeImage(pipelined=True)); every step still renders, gathers and assembles one complete image
+    img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=args.stripe_rows, want_stats=True,
+                      pipelined=world > 1)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        img.render(spp, frame_begin=0, max_bounces=depth)
-        img.gather()
+    def run_steps(n):
+        prev = None
+        for _ in range(n):
+            slot = img.render(spp, frame_begin=0, max_bounces=depth)
+            if prev is not None:
+                img.gather(prev)   # the previous step's image: its collective overlaps the render just enqueued
+            prev = slot
+        if prev is not None:
+            img.gather(prev)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     img.reset_stats()
     shim.check(lib.pt_profile_enable(dev._h, 1))
     shim.check(lib.pt_profile_reset(dev._h))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -82,7 +82,10 @@ class StripeImage:
     tensor (so the collective moves it with no staging copy) wrapped by the shim."""
 
     def __init__(self, dev: adl.Device, triangles, materials, width: int, height: int, *, world: int = 1, rank: int = 0,
-                 stripe_rows: int = 16, want_stats: bool = False):
+                 stripe_rows: int = 16, want_stats: bool = False, pipelined: bool = False):
+        """``pipelined``: two local framebuffers and two gather buffers, so that the collective of one render can run
+        while the next render is already on the GPU (``render`` returns the slot it rendered into, ``gather(slot)``
+        takes it; see ``bench.py``).  Every render must then start at frame 0 or continue its own slot's frames."""
         self.dev, self.world, self.rank = dev, int(world), int(rank)
         self.width, self.height = int(width), int(height)
         self.plan = StripePlan(height, stripe_rows, world)
@@ -93,30 +96,61 @@ class StripeImage:
         # ops / the collective run on is an event wait (wait_stream), never a host sync.
         self.stream = torch.cuda.Stream(device=self.cuda)
         shim.check(shim.load().pt_device_set_stream(dev._h, self.stream.cuda_stream))
-        self.local = torch.zeros((self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
+        self.pipelined = bool(pipelined) and self.world > 1
+        nslots = 2 if self.pipelined else 1
+        self._locals = [torch.zeros((self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda) for _ in range(nslots)]
+        self.local = self._locals[0]
         self.stream.wait_stream(torch.cuda.current_stream(self.cuda))  # the zero fill precedes the first render
         self.renderer = Renderer(dev, triangles, materials, width, height, n_ranks=world, rank=rank,
                                  stripe_rows=stripe_rows, fb_device_ptr=self.local.data_ptr(), want_stats=want_stats)
         assert self.renderer.local_rows == self.plan.local_rows(rank)
+        self._fbs = [self.renderer.fb]
+        for t in self._locals[1:]:
+            b = adl.Buffer(dtype=adl.float4)
+            b.setRawPtr(dev, t.data_ptr(), max(self.renderer.local_pixels, 1))
+            self._fbs.append(b)
+        # per slot: "its render is done" (recorded on the shim stream), "its collective has read it" (on torch's stream)
+        self._rendered = [torch.cuda.Event() for _ in range(nslots)]
+        self._collected = [None] * nslots
+        self._slot = 0       # the slot the next render goes to
+        self._last = 0       # the slot the last render went to
         self.image = None
-        self._slabs = self._gbuf = self._ibuf = None
+        self._slabs = []
+        self._gbufs = []
+        self._ibuf = None
         if rank == 0 and world > 1:
-            # gather destination and assembled image live for the object's lifetime: a render loop
+            # gather destinations and the assembled image live for the object's lifetime: a render loop
             # allocates, wraps and synchronises nothing per step
             self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=self.cuda)
-            self._slabs = torch.empty((self.world, self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
-            self._gbuf = adl.Buffer(dtype=adl.float4)
             self._ibuf = adl.Buffer(dtype=adl.float4)
-            self._gbuf.setRawPtr(dev, self._slabs.data_ptr(), self._slabs.numel() // 4)
             self._ibuf.setRawPtr(dev, self.image.data_ptr(), self.image.numel() // 4)
+            for _ in range(nslots):
+                sl = torch.empty((self.world, self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda)
+                g = adl.Buffer(dtype=adl.float4)
+                g.setRawPtr(dev, sl.data_ptr(), sl.numel() // 4)
+                self._slabs.append(sl)
+                self._gbufs.append(g)
 
-    def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> None:
-        """Enqueue frames on the shim stream.  ``self.local`` may be consumed by torch ops on the
-        current stream after ``ready()`` (or ``gather()``), without a host synchronisation."""
-        # torch work already queued on the current stream that touches self.local (a previous
-        # gather reading it, a user op) must finish before the render overwrites it
-        self.stream.wait_stream(torch.cuda.current_stream(self.cuda))
-        self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces)
+    def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> int:
+        """Enqueue frames on the shim stream; returns the slot rendered into (always 0 unless ``pipelined``).
+        ``self.local`` may be consumed by torch ops on the current stream after ``ready()`` (or ``gather()``),
+        without a host synchronisation."""
+        slot = self._slot
+        if self.pipelined:
+            # only the collective that last read THIS slot has to be over; the other slot's may still be running
+            if self._collected[slot] is not None:
+                self.stream.wait_event(self._collected[slot])
+        else:
+            # torch work already queued on the current stream that touches self.local (a previous
+            # gather reading it, a user op) must finish before the render overwrites it
+            self.stream.wait_stream(torch.cuda.current_stream(self.cuda))
+        self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces, fb=self._fbs[slot])
+        self._rendered[slot].record(self.stream)
+        self._last = slot
+        self.local = self._locals[slot]
+        if self.pipelined:
+            self._slot ^= 1
+        return slot
 
     def ready(self) -> torch.Tensor:
         """Order torch's current stream after everything enqueued on the shim stream so far and
@@ -124,18 +158,32 @@ class StripeImage:
         torch.cuda.current_stream(self.cuda).wait_stream(self.stream)
         return self.local
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Assemble the full image on rank 0 (returns it there; None elsewhere)."""
+    def gather(self, slot: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Assemble the full image of the last render (or of ``slot``) on rank 0 (returns it there; None elsewhere).
+
+        Pipelined use: ``s = img.render(...)`` of the NEXT image first, then ``img.gather(previous_slot)``: the
+        collective runs on torch's stream beside that render, the assembly kernel follows it on the shim stream."""
         cur = torch.cuda.current_stream(self.cuda)
-        cur.wait_stream(self.stream)           # renders -> collective / consumer
+        slot = self._last if slot is None else int(slot)
+        if self.pipelined:
+            cur.wait_event(self._rendered[slot])   # this slot's render -> collective (a later render may be in flight)
+        else:
+            cur.wait_stream(self.stream)           # renders -> collective / consumer
         if self.world == 1:
-            self.image = self.local[: self.height]
+            self.image = self._locals[slot][: self.height]
             return self.image
-        gather_slabs(self.local, self.world, self.rank, out=self._slabs)
+        gather_slabs(self._locals[slot], self.world, self.rank, out=self._slabs[slot] if self.rank == 0 else None)
+        if self.pipelined:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._collected[slot] = ev             # the slot may be rendered into again after this
         if self.rank != 0:
             return None
-        self.stream.wait_stream(cur)           # collective -> assembly kernel (reads _slabs)
-        shim.check(shim.load().pt_assemble_stripes(self.dev._h, self._gbuf._h, self._ibuf._h, self.width, self.height,
+        if self.pipelined:
+            self.stream.wait_event(self._collected[slot])
+        else:
+            self.stream.wait_stream(cur)           # collective -> assembly kernel (reads _slabs)
+        shim.check(shim.load().pt_assemble_stripes(self.dev._h, self._gbufs[slot]._h, self._ibuf._h, self.width, self.height,
                                                    self.plan.stripe_rows, self.world, self.plan.slab_rows, None))
         cur.wait_stream(self.stream)           # assembly -> whoever consumes self.image
         return self.image
@@ -149,10 +197,10 @@ class StripeImage:
         return self.renderer.read_stats()
 
     def release(self) -> None:
-        for b in (self._gbuf, self._ibuf):
+        for b in self._gbufs + [self._ibuf] + self._fbs[1:]:
             if b is not None:
                 b.release()
-        self._gbuf = self._ibuf = None
+        self._gbufs, self._ibuf, self._fbs = [], None, self._fbs[:1]
         self.renderer.release()
         # hand the device handle back to its own stream before the torch stream can die
         shim.check(shim.load().pt_device_set_stream(self.dev._h, None))

@@ -97,8 +97,9 @@ class Renderer:
         self.frames_done = 0
 
     def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = BOUNCES,
-               sync: Optional[adl.SyncObject] = None) -> None:
-        """Enqueue frames [frame_begin, frame_begin+frames) (default: continue after the last call)."""
+               sync: Optional[adl.SyncObject] = None, fb: Optional[adl.Buffer] = None) -> None:
+        """Enqueue frames [frame_begin, frame_begin+frames) (default: continue after the last call).
+        ``fb``: another framebuffer of the same size to render into (a pipeline's second buffer)."""
         if frame_begin is None:
             frame_begin = self.frames_done
         p = shim.RenderParams()
@@ -107,7 +108,7 @@ class Renderer:
         p.max_bounces = int(max_bounces)
         p.num_triangles, p.num_materials = self.num_triangles, self.num_materials
         p.stripe_rows, p.n_ranks, p.rank = self.stripe_rows, self.n_ranks, self.rank
-        shim.check(shim.load().pt_render_frames(self.dev._h, self.tbuf._h, self.mbuf._h, self.fb._h, ctypes.byref(p),
+        shim.check(shim.load().pt_render_frames(self.dev._h, self.tbuf._h, self.mbuf._h, (fb or self.fb)._h, ctypes.byref(p),
                                                 self.stats._h if self.stats else None,
                                                 sync._h if sync is not None else None))
         self.frames_done = frame_begin + frames

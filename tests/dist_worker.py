@@ -2,7 +2,7 @@
 StripeImage, takes part in the gather, and -- on rank 0 -- saves the assembled image.
 
 usage (environment: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT):
-    python dist_worker.py <nccl|gloo> <out.npy> W H frames stripe_rows
+    python dist_worker.py <nccl|gloo> <out.npy> W H frames stripe_rows [pipelined]
 backend gloo: every rank uses device (LOCAL_RANK % device_count) -- ranks may share one GPU.
 """
 import os
@@ -32,13 +32,25 @@ def main():
     assert adl.init(adl.TYPE_HIP)
     dev = adl.DeviceUtils.allocate(adl.TYPE_HIP, adl.Config(dev_idx))
     tris, mats = scene.load_model()
-    img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=stripe)
-    # two halves, the second enqueued right behind the first gather: exercises render-after-gather ordering
-    half = frames // 2
-    img.render(half, frame_begin=0)
-    img.gather()
-    img.render(frames - half, frame_begin=half)
-    image = img.gather()
+    pipelined = len(sys.argv) > 7 and sys.argv[7] == "pipelined"
+    img = StripeImage(dev, tris, mats, W, H, world=world, rank=rank, stripe_rows=stripe, pipelined=pipelined)
+    if pipelined:
+        # bench.py's loop: three complete images, each gathered after the NEXT render has been enqueued; the images of
+        # slots 0, 1, 0 have 1, 2 and `frames` frames, the last gather must deliver the last one
+        prev = None
+        for n in (1, 2, frames):
+            slot = img.render(n, frame_begin=0)
+            if prev is not None:
+                img.gather(prev)
+            prev = slot
+        image = img.gather(prev)
+    else:
+        # two halves, the second enqueued right behind the first gather: exercises render-after-gather ordering
+        half = frames // 2
+        img.render(half, frame_begin=0)
+        img.gather()
+        img.render(frames - half, frame_begin=half)
+        image = img.gather()
     if rank == 0:
         torch.cuda.synchronize()
         import numpy as np

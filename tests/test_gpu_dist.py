@@ -80,7 +80,7 @@ def test_stripe_image_is_ordered_against_torch_without_host_sync(device, cornell
         img.release()
 
 
-def _run_world(world, backend, tmp_path, ndev_needed):
+def _run_world(world, backend, tmp_path, ndev_needed, extra=()):
     port = _free_port()
     out = str(tmp_path / "image.npy")
     procs = []
@@ -89,7 +89,7 @@ def _run_world(world, backend, tmp_path, ndev_needed):
         env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), backend, out,
-                                       str(W), str(H), str(FRAMES), str(STRIPE)], env=env,
+                                       str(W), str(H), str(FRAMES), str(STRIPE)] + list(extra), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -109,6 +109,18 @@ def test_world2_processes_share_one_gpu_gloo(device, cornell, tmp_path):
     want = _single_gpu_image(device, cornell)
     got = _run_world(2, "gloo", tmp_path, 1)
     assert_fb_equal(got.reshape(-1, 4), want, "world-2 (gloo through the host) vs one process")
+
+
+def test_world2_pipelined_gathers(device, cornell, tmp_path):
+    """StripeImage(pipelined=True), the loop bench.py --gpus N times: every gather is issued after the NEXT render has
+    been enqueued into the other framebuffer; the last gather must deliver the last image (gloo through the host on a
+    one-GPU box; RCCL when two devices are visible)."""
+    from oclpathtracer_amd import shim
+
+    want = _single_gpu_image(device, cornell)
+    two = shim.load().pt_device_count() >= 2
+    got = _run_world(2, "nccl" if two else "gloo", tmp_path, 2 if two else 1, extra=("pipelined",))
+    assert_fb_equal(got.reshape(-1, 4), want, "world-2 pipelined gathers vs one process")
 
 
 def test_world2_nccl(device, cornell, tmp_path):
