@@ -128,7 +128,8 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=16)
-    ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--stripe-rows", type=int, default=4,
+                    help="rows per image stripe of the N-rank split (4: the ranks' shares of configs[2] are equal to 1 %%; 16: 2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] / configs[4] legs of extra.configs")
     ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 4 packed")
