@@ -229,6 +229,9 @@ def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):
              "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_,
              "traffic_basis": (src + ": measured bytes fetched beyond the L2 per ray x rays of this launch") if src else None,
              "measured_fetch_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+             "measured_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,  # the bytes that really cross the L2's miss path
+             "frac_note": "`frac` uses the ALGORITHMIC bytes (the contract): it exceeds the measured one, and may exceed 1, because L1 / L2 serve "
+                          "46 % of the line requests; `measured_frac` = `traffic` / time / peak is the share of the HBM figure the kernel really pulls",
              "note": "algorithmic = 80 B per eight-child node entered + 48 B per triangle tested + 12 B radiance per sample; the upper "
                      "tree levels are served by L1 / L2, so the algorithmic rate exceeds what crosses the L2's miss path "
                      "(`traffic`, measured: FETCH_SIZE x 2).  PMC (profiles/r02/pmc_soup_lbvh_cw8.txt): 29.7 L2 misses per ray = 54 G line "
