@@ -6,19 +6,20 @@
 //
 //   pt_prep_kernel   once per scene upload: Triangle -> {p1, e1, e2, n, id}; for scenes made of
 //                    quads also the slack and the packed table of the pass-1 filter
-//   pt_trace_kernel  persistent waves; every LANE owns one path at a time and, when its path
-//                    ends, immediately starts the next (pixel, frame) sample of the wave's current
-//                    batch of a global queue (ballot + mbcnt compaction; the batch's camera rays
-//                    are generated 64 wide into LDS when the batch is taken), so the closest-hit
-//                    search always runs with a full exec mask.  The search is two-pass: pass 1
-//                    walks the triangles with a wave-uniform index (per-triangle constants are
-//                    scalar loads consumed as SGPR operands) and keeps, per lane, a bit mask of
-//                    the triangles that MAY pass the cull and u tests -- a conservative filter,
-//                    in its strongest form one packed FMA chain deciding four triangles
-//                    (pt_quad3_pass1); pass 2 lets every lane run the exact reference test on its
-//                    own ~3 survivors, fetched per lane from an LDS copy of the records.  Scenes
-//                    of 512 triangles or more walk an LBVH instead (pt_trace_bvh_body, pt_bvh.hip).
-//                    Path radiance goes to rad[frame][pixel].
+//   pt_trace_kernel  persistent waves; every LANE holds one path at a time.  A wave takes batches of consecutive
+//                    samples off a global queue and keeps up to 64 PARKED paths in LDS: lanes whose path has
+//                    ended take a parked one; when the pool is empty the wave parks its live paths and starts
+//                    64 fresh samples -- 64 consecutive pixels, camera rays at full lane width, a coherent
+//                    first bounce (pt_start_fresh, pt_pool_push / pt_pool_pop).  The closest-hit search is
+//                    two-pass: pass 1 walks the triangles with a wave-uniform index (per-triangle constants are
+//                    scalar loads consumed as SGPR operands) and keeps, per lane, a bit mask of the triangles
+//                    that MAY pass the cull and u tests -- a conservative filter, in its strongest form one
+//                    packed FMA chain deciding four triangles (pt_quad3_pass1; fresh primary rays read their
+//                    masks from a per-pixel table instead: pt_primary_mask_kernel); pass 2 lets every lane run
+//                    the exact reference test on its own survivors, fetched per lane from an LDS copy of the
+//                    records, and balances the last ones across the wave's lanes (pt_tail_round).  Scenes of
+//                    512 triangles or more walk an LBVH instead (pt_trace_bvh_body, pt_bvh_step, pt_bvh.hip).
+//                    Path radiance goes to rad[frame][pixel] (three floats).
 //   pt_fold_kernel   per pixel channel, in ascending frame order, replays the reference's
 //                    gamma -> mean -> degamma arithmetic (GenerateColors.cl:314-321) over the
 //                    staged radiances: bit-identical to frame-by-frame launches.
