@@ -340,7 +340,8 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (cornellbox.bin scene, seeded per-pixel RNG of the reference)",
             "config": {"workload": "cornellbox.bin %dx%d, %d spp, depth %d, full path (BASELINE configs[2])" % (W, H, spp, depth),
-                       "sharding": "%d-row image stripes round-robin over %d rank(s), RCCL gather to rank 0" % (args.stripe_rows, world),
+                       "sharding": "%d-row image stripes round-robin over %d rank(s), RCCL gather to rank 0%s" % (
+                           args.stripe_rows, world, " (two framebuffers per rank: the gather of a step runs beside the next step's render)" if world > 1 else ""),
                        "rays_per_sample": total_rays / total_samples, "timed_region_s": dt},
         }
         if rehearsal:
