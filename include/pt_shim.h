@@ -37,7 +37,12 @@ enum pt_status {
     PT_ERR_HIP = 4,        /* a HIP runtime call failed                               */
     PT_ERR_NOT_FOUND = 5,  /* unknown kernel (Adl: getKernel returns 0)               */
     PT_ERR_ARGS = 6,       /* launch arguments do not match the kernel's signature    */
-    PT_ERR_RANGE = 7       /* offset/size outside a buffer                            */
+    PT_ERR_RANGE = 7,      /* offset/size outside a buffer                            */
+    PT_ERR_TRAVERSAL = 8   /* an LBVH search was cut short (stack capacity or step budget): the render's pixels
+                              may be wrong and must be discarded.  The reference's brute force
+                              (GenerateColors.cl:137-154) cannot skip a triangle, so this is an error, never a
+                              silent approximation; it cannot occur with a hierarchy the library built
+                              (csrc/pt_kernels.hip, PT_BVH_STACK) unless PT_OPT_BVH_STACK_LIMIT lowers the stack */
 };
 
 typedef struct pt_device_s* pt_device_t;
@@ -130,7 +135,11 @@ enum pt_option {
      * per pixel, a conservative candidate set of triangles its primary rays can meet (the camera is fixed:
      * GenerateColors.cl:265-272), and waves of fresh primary rays skip the pass-1 filter.  0 = off (A/B timing,
      * parity tests).  Identical pixels either way. */
-    PT_OPT_PRIMARY_MASKS = 7
+    PT_OPT_PRIMARY_MASKS = 7,
+    /* test hook of the LBVH's overflow report: the number of stack entries a ray's search may use (1..64; default 64,
+     * which no hierarchy built by the library can exceed).  A search that needs more sets a sticky device flag and the
+     * render returns PT_ERR_TRAVERSAL.  LBVH renders synchronise with the device before returning to read that flag. */
+    PT_OPT_BVH_STACK_LIMIT = 8
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

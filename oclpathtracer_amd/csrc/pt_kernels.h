@@ -109,6 +109,8 @@ struct PtTraceParams {
     int32_t nbig;
     const uint2* pmask;           // quad mode 3, <= 64 triangles: per local pixel the primary rays' candidate masks of the two
                                   // 32-triangle chunks (pt_primary_mask_kernel); null = run pass 1 for primary rays too
+    unsigned int* bvh_flags;      // accel = BVH: one device word of sticky PT_BVH_FLAG_* bits (a search was cut short), zeroed by the host
+    int32_t bvh_stack_limit;      //              stack entries a lane may use, <= PT_BVH_STACK (lower only to test the overflow report)
 };
 
 struct PtFoldParams {

@@ -1365,8 +1365,13 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 //   * a step budget and index checks make a damaged hierarchy end the search instead of hanging or faulting the GPU.
 // TALLY: the measurement variant (PT_OPT_BVH_TALLY) adds the search's work counters to stats[2..4]: nodes entered,
 // triangles tested (both per lane), node and triangle phases executed by the waves.  Never the timed kernel.
+// Stack capacity.  An entry is a node's group with children still to enter, so the stack is never deeper than the
+// eight-child hierarchy, whose nodes are binary nodes of the radix tree (pt_bvh.hip) in ancestor order: at most the 62 levels
+// of a radix tree over 62-bit keys (30-bit Morton code << 32 | index).  64 entries cannot overflow on a hierarchy the builder
+// made; PtTraceParams::bvh_stack_limit (<= PT_BVH_STACK) lowers the capacity for the test of the overflow report.
+// (The overflow array lives in scratch; one of fewer than 64 dwords would be promoted to registers.)
 #ifndef PT_BVH_STACK
-#define PT_BVH_STACK 48  // (an overflow array of fewer than 64 dwords is promoted to registers: 126 VGPRs)
+#define PT_BVH_STACK 64
 #endif
 #ifndef PT_BVH_LDS_STACK
 #define PT_BVH_LDS_STACK 8
@@ -1415,11 +1420,11 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
 }
 
 // a lane's search state (pt_bvh_step): the closest hit so far, the group of node children still to enter (gbase, gm = hits by
-// slot | imask << 8), the leaf children still to test (tbase, tm = hits by slot | lmask << 8, of node tnode), the stack depth
+// slot | imask << 8), the stack depth.  (Leaf children never wait in the lane: they go to the wave's pair ring, pt_bvh_round.)
 struct PtBvhLane {
     float tmax, hu, hv;
     int hidx;
-    unsigned gbase, gm, tbase, tm, tnode;
+    unsigned gbase, gm;
     unsigned oct;  // bit a set: the ray runs towards +a (children on the low side come first)
     int sp;
     float ix, iy, iz;
@@ -1437,114 +1442,198 @@ PTK_DEV void pt_bvh_lane_start(PtBvhLane& L, const f3& d, int ntri)
     L.oct = (L.ix < 0.0f ? 0u : 1u) | (L.iy < 0.0f ? 0u : 2u) | (L.iz < 0.0f ? 0u : 4u);
     L.gbase = 0u;  // the root (node 0) as a group of one: slot 0
     L.gm = 1u | (1u << 8);
-    L.tbase = 0u; L.tm = 0u; L.tnode = 0u;
     L.sp = 0;
-    L.budget = 2u * (unsigned)ntri + 64u;
+    // every node is entered at most once and a hierarchy over ntri leaves has fewer than ntri nodes: a valid tree never
+    // uses the budget up (PT_BVH_FLAG_BUDGET reports a damaged one)
+    L.budget = (unsigned)ntri + 64u;
 }
 
 typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
 
-// one step of the wave: a triangle phase when enough lanes hold pending leaves, then a node phase (see above).  stk: this
-// lane's stack in LDS, ovf: its overflow in scratch, nxt: the 2 KB child-order table
+// sticky bits of *PtTraceParams::bvh_flags: the search of some ray was CUT SHORT -- its closest hit may be wrong.  The host
+// turns them into PT_ERR_TRAVERSAL (pt_render_frames); neither can happen with a hierarchy pt_bvh.hip built (see PT_BVH_STACK)
+#define PT_BVH_FLAG_STACK 1u   // a group had to be pushed beyond the stack's capacity
+#define PT_BVH_FLAG_BUDGET 2u  // more node visits than the hierarchy has nodes
+
+// ---- the leaves: (leaf record, ray lane) pairs, tested 64 at a time --------------------------------------------------
+// With 64 incoherent lanes some lane meets a leaf at nearly every step, and each lane meets one only every ~10 nodes.  Round
+// 2 let a lane WAIT with its leaves until 8 lanes had some and then ran the ~70-instruction exact test for those ~10 lanes
+// (16 % of the lanes busy in a triangle phase, 74 % in a node phase: waiting lanes enter no nodes).  Now a lane never waits:
+// the leaf children its node test hits are appended, as (record, ray lane) pairs, to the wave's ring in LDS -- the one the
+// brute-force search's tail uses (pt_tail_round) -- and the lane goes on to its next node; as soon as PT_BVH_RING_MIN pairs
+// are pending the wave tests up to 64 of them at once, one pair per lane whoever owns the ray: the ray travels by
+// ds_bpermute, the candidate's key (t bits << 32 | triangle << 6 | testing lane) goes to the ray's slot with one
+// ds_min_u64, and the owner picks (t, index) from its slot and (u, v) from the lane that tested the winner.  The reference's
+// closest hit is the lexicographic minimum of (t, index) over the triangles that pass the exact test (strict t < tmax in an
+// ascending loop, GenerateColors.cl:125,145-151), and the key's order IS that order (t > 0: float bits are monotone), so
+// the slot, initialised with the ray's incumbent (tmax, hidx), ends up holding the reference's winner whatever the order of
+// the tests.  A ray's tmax now shrinks a few steps later than it could (its leaf waits in the ring), which costs some node
+// visits; PT_BVH_RING_MIN trades that against the rounds' occupancy.
+// pair = in-node flag << 31 | (node or leaf-record index) << 6 | ray lane: a node's first leaf has a copy of its record in
+// the node's own line (bytes 80..127: no second request); indices below 2^25 (checked by the host)
+#ifndef PT_BVH_RING_MIN
+#define PT_BVH_RING_MIN 32u
+#endif
+template <bool DET_BOUNDED>
+PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsigned cnt, unsigned lane, const f3& o, const f3& d,
+                          unsigned n_nodes, int ntri)
+{
+    // every lane, as the owner of a ray, publishes its incumbent; a slot nobody improves reads back unchanged
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(L.tmax) << 32) |
+                                  (unsigned long long)(((((unsigned)L.hidx) & 0x3ffffffu) << 6) | lane);
+    tl.keys[lane] = k0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool act = lane < cnt;
+    const unsigned e = act ? tl.list[(tl.rd + lane) & (PT_TAIL_LIST - 1u)] : 0u;
+    const unsigned ray = e & 63u, idx = (e >> 6) & 0x1ffffffu;
+    const bool in_node = (e >> 31) != 0u;
+    const unsigned a = ray << 2;
+    const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
+    const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
+    const bool valid = act & (in_node ? idx < n_nodes : idx < (unsigned)ntri);
+    const float4* qp = !valid ? reinterpret_cast<const float4*>(P.bvh)
+                     : in_node ? reinterpret_cast<const float4*>(P.bvh + idx) + 5 : reinterpret_cast<const float4*>(P.ltris + idx);
+    const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+    PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
+    r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
+    r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
+    r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
+    const unsigned tri = __float_as_uint(q2.y) & 0x3ffffffu;
+    float t, u, v;
+    bool ok;
+    {   // the reference's test (:96-125) without the running tmax: the slot's minimum applies that
+        float pvx = pt_fma(pd.y, r.e2z, -(pd.z * r.e2y));
+        float pvy = pt_fma(pd.z, r.e2x, -(pd.x * r.e2z));
+        float pvz = pt_fma(pd.x, r.e2y, -(pd.y * r.e2x));
+        float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
+        float inv_det = DET_BOUNDED ? pt_rcp(det) : 1.0f / det;  // pt_rcp: exact, range-checked (det may be anything here)
+        float tvx = po.x - r.p1x, tvy = po.y - r.p1y, tvz = po.z - r.p1z;
+        u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
+        ok = !(det < 1e-8f) & !(-det > 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109
+        float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
+        float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
+        float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
+        v = pt_fma(pd.z, qvz, pt_fma(pd.y, qvy, pd.x * qvx)) * inv_det;
+        ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
+        t = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
+        ok &= (t > 0.0f) & (t < 1e20f);  // :125 against the initial tmax (:141)
+    }
+    if (ok & valid) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((tri << 6) | lane);
+        __hip_atomic_fetch_min(tl.keys + ray, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long slot = tl.keys[lane];
+    const unsigned from = ((unsigned)slot & 63u) << 2;
+    const float pu = pt_from_lane(from, u), pv = pt_from_lane(from, v);
+    if (slot != k0) {  // (t, index) < the incumbent's: the new closest hit
+        L.tmax = __uint_as_float((unsigned)(slot >> 32));
+        L.hidx = (int)(((unsigned)slot >> 6) & 0x3ffffffu);
+        L.hu = pu;
+        L.hv = pv;
+    }
+    tl.rd += cnt;
+}
+
+// one step of the wave: a node phase for every traversing lane (trav: the lane still has nodes to enter), its leaf hits to the
+// ring, a round when enough pairs are pending.  stk: this lane's stack in LDS, ovf: its overflow in scratch, nxt: the 2 KB
+// child-order table
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const f3& o, const f3& d, pt_lds_u32* stk, unsigned* ovf,
-                         const pt_lds_u8* nxt, unsigned n_nodes, int ntri, unsigned& c_nodes, unsigned& c_leaves,
+                         const pt_lds_u8* nxt, PtTail& tl, unsigned lane, unsigned n_nodes, int ntri, unsigned& c_nodes, unsigned& c_leaves,
                          unsigned long long& c_steps, unsigned long long& c_tsteps)
 {
-    // ---- one step of the wave ----------------------------------------------------------------
-    const bool want_tri = trav && (L.tm & 255u) != 0u;
-    const unsigned n_tri = (unsigned)__popcll(__ballot(want_tri));
-    if (n_tri >= (unsigned)PT_BVH_TRI_LANES || (n_tri != 0u && __ballot(trav && !want_tri) == 0ull)) {
-        if (TALLY) ++c_tsteps;
-        if (want_tri) {
-            if (TALLY) ++c_leaves;
-            const unsigned slot = (unsigned)__builtin_ctz(L.tm & 255u);
-            L.tm &= L.tm - 1u;  // (the lowest set bit is a hit bit: the hits are the low byte and not empty)
-            const unsigned rank = (unsigned)__popc((L.tm >> 8) & ((1u << slot) - 1u));
-            const unsigned idx = L.tbase + rank;
-            if (idx < (unsigned)ntri) {
-                // a node's first leaf has a copy of its record in the node's own line (bytes 80..127): no second request
-                const float4* qp = rank == 0u ? reinterpret_cast<const float4*>(P.bvh + L.tnode) + 5
-                                              : reinterpret_cast<const float4*>(P.ltris + idx);
-                const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
-                PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
-                r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
-                r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
-                r.e2x = q1.z; r.e2y = q1.w; r.e2z = q2.x;
-                pt_tri_exact_unordered<DET_BOUNDED>(r, (int)__float_as_uint(q2.y), o, d, L.tmax, L.hu, L.hv, L.hidx);
-            }
-            --L.budget;
+    unsigned ht = 0u, lmask = 0u, lbase = 0u, node = 0u;
+    if (TALLY) ++c_steps;
+    if (trav) {
+        if (TALLY) ++c_nodes;
+        if ((L.gm & 255u) == 0u) {  // (then L.sp > 0)
+            L.sp = L.sp > 0 ? L.sp - 1 : 0;
+            if (L.sp < PT_BVH_LDS_STACK) { L.gbase = stk[(2 * L.sp) * PT_TRACE_THREADS]; L.gm = stk[(2 * L.sp + 1) * PT_TRACE_THREADS]; }
+            else { L.gbase = ovf[2 * (L.sp - PT_BVH_LDS_STACK)]; L.gm = ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1]; }
         }
-    }
-    // (a lane that has just tested its last pending triangle enters a node in the same step)
-    if (trav && ((L.tm & 255u) == 0u) && ((L.gm & 255u) == 0u) && L.sp == 0) trav = false;  // nothing left: the closest hit stands
-    const bool want_node = trav && (L.tm & 255u) == 0u;
-    if (__ballot(want_node) != 0ull) {
-        if (TALLY) ++c_steps;
-        if (want_node) {
-            if (TALLY) ++c_nodes;
-            if ((L.gm & 255u) == 0u) {  // (then L.sp > 0)
-                L.sp = L.sp > 0 ? L.sp - 1 : 0;
-                if (L.sp < PT_BVH_LDS_STACK) { L.gbase = stk[(2 * L.sp) * PT_TRACE_THREADS]; L.gm = stk[(2 * L.sp + 1) * PT_TRACE_THREADS]; }
-                else { L.gbase = ovf[2 * (L.sp - PT_BVH_LDS_STACK)]; L.gm = ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1]; }
-            }
-            // the group's next child: highest priority first; its slot, its rank among the node children
-            const unsigned slot = nxt[(L.oct << 8) | (L.gm & 255u)];
-            L.gm &= ~(1u << slot);
-            const unsigned node = L.gbase + (unsigned)__popc((L.gm >> 8) & ((1u << slot) - 1u));
-            unsigned h = 0u, imask = 0u, lmask = 0u, cbase = 0u, lbase = 0u;
-            if (node < n_nodes) {
-                const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
-                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
-                const unsigned meta = w0.w;
-                const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
-                            sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-                imask = meta >> 24;
-                cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
-                // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
-                // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
-                // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
-                const float kx = sx * L.ix, ky = sy * L.iy, kz = sz * L.iz;
-                const float cx = (__uint_as_float(w0.x) - o.x) * L.ix, cy = (__uint_as_float(w0.y) - o.y) * L.iy,
-                            cz = (__uint_as_float(w0.z) - o.z) * L.iz;
-                // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
-                // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
-                const bool px = (L.oct & 1u) != 0u, py = (L.oct & 2u) != 0u, pz = (L.oct & 4u) != 0u;
-                const unsigned nx0 = px ? w2.x : w3.z, nx1 = px ? w2.y : w3.w, fx0 = px ? w3.z : w2.x, fx1 = px ? w3.w : w2.y;
-                const unsigned ny0 = py ? w2.z : w4.x, ny1 = py ? w2.w : w4.y, fy0 = py ? w4.x : w2.z, fy1 = py ? w4.y : w2.w;
-                const unsigned nz0 = pz ? w3.x : w4.z, nz1 = pz ? w3.y : w4.w, fz0 = pz ? w4.z : w3.x, fz1 = pz ? w4.w : w3.y;
+        // the group's next child: highest priority first; its slot, its rank among the node children
+        const unsigned slot = nxt[(L.oct << 8) | (L.gm & 255u)];
+        L.gm &= ~(1u << slot);
+        node = L.gbase + (unsigned)__popc((L.gm >> 8) & ((1u << slot) - 1u));
+        unsigned h = 0u, imask = 0u, cbase = 0u;
+        if (node < n_nodes) {
+            const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
+            const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
+#ifdef PT_EXP_EXTRA_LOAD  // EXPERIMENT (never shipped): one more 16-byte load of the node's own line per visit
+            { const uint4 wx = np[5]; asm volatile("" :: "v"(wx.x), "v"(wx.y), "v"(wx.z), "v"(wx.w)); }
+#endif
+            const unsigned meta = w0.w;
+            const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
+                        sz = __uint_as_float(((meta >> 16) & 255u) << 23);
+            imask = meta >> 24;
+            cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
+            // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
+            // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
+            // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
+            const float kx = sx * L.ix, ky = sy * L.iy, kz = sz * L.iz;
+            const float cx = (__uint_as_float(w0.x) - o.x) * L.ix, cy = (__uint_as_float(w0.y) - o.y) * L.iy,
+                        cz = (__uint_as_float(w0.z) - o.z) * L.iz;
+            // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
+            // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
+            const bool px = (L.oct & 1u) != 0u, py = (L.oct & 2u) != 0u, pz = (L.oct & 4u) != 0u;
+            const unsigned nx0 = px ? w2.x : w3.z, nx1 = px ? w2.y : w3.w, fx0 = px ? w3.z : w2.x, fx1 = px ? w3.w : w2.y;
+            const unsigned ny0 = py ? w2.z : w4.x, ny1 = py ? w2.w : w4.y, fy0 = py ? w4.x : w2.z, fy1 = py ? w4.y : w2.w;
+            const unsigned nz0 = pz ? w3.x : w4.z, nz1 = pz ? w3.y : w4.w, fz0 = pz ? w4.z : w3.x, fz1 = pz ? w4.w : w3.y;
 #define PT_B8(lo_, hi_, k) (float)((((k) < 4 ? (lo_) : (hi_)) >> (8 * ((k) & 3))) & 255u)
 #pragma unroll
-                for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
-                    const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
-                    const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
-                    const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
-                    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-                    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, L.tmax));
-                    h = pt_push_flag(h, PT_LANES(tn <= tf));
-                }
+            for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
+                const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
+                const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
+                const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, L.tmax));
+                h = pt_push_flag(h, PT_LANES(tn <= tf));
+            }
 #undef PT_B8
-            }
-            const unsigned hn = h & imask, ht = h & lmask;
-            // the rest of the old group goes on the stack, the children just hit become the current group
-            if ((L.gm & 255u) != 0u && hn != 0u) {
-                if (L.sp < PT_BVH_LDS_STACK) { stk[(2 * L.sp) * PT_TRACE_THREADS] = L.gbase; stk[(2 * L.sp + 1) * PT_TRACE_THREADS] = L.gm; }
-                else if (L.sp < PT_BVH_STACK) { ovf[2 * (L.sp - PT_BVH_LDS_STACK)] = L.gbase; ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1] = L.gm; }
-                L.sp = L.sp < PT_BVH_STACK ? L.sp + 1 : L.sp;
-            }
-            if (hn != 0u) {
-                L.gbase = cbase;
-                L.gm = hn | (imask << 8);
-            }
-            L.tbase = lbase;
-            L.tnode = node;
-            L.tm = ht | (lmask << 8);
-            --L.budget;
+        }
+        const unsigned hn = h & imask;
+        ht = h & lmask;
+        // the rest of the old group goes on the stack, the children just hit become the current group
+        if ((L.gm & 255u) != 0u && hn != 0u) {
+            if (L.sp < PT_BVH_LDS_STACK) { stk[(2 * L.sp) * PT_TRACE_THREADS] = L.gbase; stk[(2 * L.sp + 1) * PT_TRACE_THREADS] = L.gm; }
+            else if (L.sp < (int)P.bvh_stack_limit) { ovf[2 * (L.sp - PT_BVH_LDS_STACK)] = L.gbase; ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1] = L.gm; }
+            if (L.sp < (int)P.bvh_stack_limit) ++L.sp;
+            else atomicOr(P.bvh_flags, PT_BVH_FLAG_STACK);  // the group is lost: the host reports the render as failed
+        }
+        if (hn != 0u) {
+            L.gbase = cbase;
+            L.gm = hn | (imask << 8);
+        }
+        --L.budget;
+        // a lane with nothing left to enter is done with the nodes (its last leaves may still be in the ring)
+        if (((L.gm & 255u) == 0u) && L.sp == 0) trav = false;
+        if ((int)L.budget <= 0) { if (trav) atomicOr(P.bvh_flags, PT_BVH_FLAG_BUDGET); trav = false; }
+    }
+    // ---- the leaf children just hit join the wave's pending pairs ----------------------------
+    for (pt_lanes has = PT_LANES(ht != 0u); has != 0ull; has = PT_LANES(ht != 0u)) {
+        if (ht != 0u) {
+            if (TALLY) ++c_leaves;
+            const unsigned slot = (unsigned)__builtin_ctz(ht);
+            ht &= ht - 1u;
+            const unsigned rank = (unsigned)__popc(lmask & ((1u << slot) - 1u));
+            const unsigned pair = rank == 0u ? (0x80000000u | (node << 6) | lane) : (((lbase + rank) << 6) | lane);
+            tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = pair;
+        }
+        tl.wr += (unsigned)__popcll(has);
+        if (tl.wr - tl.rd >= 64u) {  // (room for the next 64)
+            if (TALLY) ++c_tsteps;
+            pt_bvh_round<DET_BOUNDED>(P, L, tl, 64u, lane, o, d, n_nodes, ntri);
         }
     }
-    // a lane with nothing left to enter or test has its closest hit
-    if (trav && ((L.tm & 255u) == 0u) && ((L.gm & 255u) == 0u) && L.sp == 0) trav = false;
-    if (trav && (int)L.budget <= 0) trav = false;
+    if (tl.wr - tl.rd >= (unsigned)PT_BVH_RING_MIN) {
+        if (TALLY) ++c_tsteps;
+        pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, o, d, n_nodes, ntri);
+    }
 }
 
 template <bool DET_BOUNDED, bool TALLY>
@@ -1600,20 +1689,31 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     unsigned n_rays = 0, n_samples = 0;
     PtBvhLane L;  // the search's state
     L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1;
-    L.gbase = L.gm = L.tbase = L.tm = L.tnode = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
+    L.gbase = L.gm = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
     unsigned c_nodes = 0, c_leaves = 0;
     unsigned long long c_steps = 0, c_tsteps = 0;
 
     for (;;) {
         if ((unsigned)__popcll(__ballot(trav)) <= (unsigned)PT_BVH_REFILL) {
+            // the pending pairs first: a lane that has no nodes left has its closest hit only once its leaves are tested
+            if (tl.wr != tl.rd) {
+                if (TALLY) ++c_tsteps;
+                pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, s.o, s.d, n_nodes, ntri);
+            }
             if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx, n_rays, n_samples);
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
             const bool start = alive && !trav;
             if (__ballot(start) != 0ull) {
                 if (start) { L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1; }
+#ifdef PT_EXP_NOBIG  // EXPERIMENT (never shipped; wrong pixels): what the brute-force search of the big triangles costs
+                if (false) {
+#else
                 if (P.nbig > 0) {
-                    // the triangles outside the hierarchy, in ascending index order; hp = position in their table
+#endif
+                    // the triangles outside the hierarchy, in ascending index order; hp = position in their table.  (Its tail
+                    // shares the key slots with pt_bvh_round and expects them empty: the ring has just been flushed.)
                     int hp = -1;
+                    tl.keys[lane] = ~0ull;
                     pt_intersect_two_pass<DET_BOUNDED, 1, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, L.tmax, L.hu, L.hv, hp, 0.0f, 0.0f,
                                                                  nullptr, 0.0f, 0.0f, tl, lane);
                     if (start && hp >= 0) L.hidx = P.bigidx[hp];
@@ -1625,7 +1725,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             }
             if (__ballot(alive) == 0ull) break;
         }
-        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, n_nodes, ntri, c_nodes, c_leaves, c_steps, c_tsteps);
+        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_nodes, ntri, c_nodes, c_leaves, c_steps, c_tsteps);
     }
 
     if (TALLY && P.stats) {

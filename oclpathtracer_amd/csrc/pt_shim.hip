@@ -86,7 +86,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally, opt_pmask;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally, opt_pmask, opt_bvh_stack;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -218,12 +218,13 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_quads = 0;
     d->opt_accel = 0;
     d->opt_pmask = PT_DEFAULT_PRIMARY_MASKS;
+    d->opt_bvh_stack = 64;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
         hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc(&d->counters, PT_MAX_CHUNKS * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
         hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
@@ -367,6 +368,10 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
     case PT_OPT_PRIMARY_MASKS:
         d->opt_pmask = value ? 1 : 0;
         return PT_OK;
+    case PT_OPT_BVH_STACK_LIMIT:
+        if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "the LBVH stack limit must be 1..64");
+        d->opt_bvh_stack = value;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -383,6 +388,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_ACCEL: return d->opt_accel;
     case PT_OPT_BVH_TALLY: return d->opt_tally;
     case PT_OPT_PRIMARY_MASKS: return d->opt_pmask;
+    case PT_OPT_BVH_STACK_LIMIT: return d->opt_bvh_stack;
     default: return -1;
     }
 }
@@ -708,8 +714,9 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->prep_capacity = cap;
         d->prep_src = nullptr;
     }
-    // wrapped (caller-owned) memory can change behind our back: always re-prepare it
-    if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned) return PT_OK;
+    // wrapped (caller-owned) memory can change behind our back, and so can a buffer whose device pointer has been handed
+    // out (pt_buffer_device_ptr: writes through it bump no version): always re-prepare those
+    if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned && !tris->exposed) return PT_OK;
     HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->det_bound_dev, d->stream));
     unsigned int words[PT_PREP_WORDS] = { 0u, 1u, 0x7fc00000u, 1u };
     HIP_TRY(hipMemcpyAsync(words, d->det_bound_dev, sizeof words, hipMemcpyDeviceToHost, d->stream));
@@ -815,6 +822,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
     if (!use_bvh && rp.num_triangles >= (1 << 26))
         return fail(PT_ERR_INVALID, "the brute-force search packs a triangle index in 26 bits: use PT_OPT_ACCEL 0 or 2 for %d triangles", rp.num_triangles);
+    if (use_bvh && rp.num_triangles >= (1 << 25))
+        return fail(PT_ERR_INVALID, "the LBVH search packs a node / leaf index in 25 bits: %d triangles are too many", rp.num_triangles);
 
     // frames per chunk: radiance staging is 12 B x pixels x frames
     // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
@@ -847,6 +856,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         d->rad_bytes = need;
     }
     HIP_TRY(hipMemsetAsync(d->counters, 0, (size_t)nchunks * sizeof(unsigned int), d->stream));
+    unsigned int* const bvh_flags = d->counters + PT_MAX_CHUNKS;
+    if (use_bvh) HIP_TRY(hipMemsetAsync(bvh_flags, 0, sizeof(unsigned int), d->stream));
     // primary-ray candidate masks: quad scenes of up to 64 triangles on the brute-force path (PT_OPT_PRIMARY_MASKS)
     const int quads_sel = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
     const bool use_pmask = d->opt_pmask && quads_sel == 3 && !use_bvh && rp.num_triangles <= 64 && d->prep_det_bounded;
@@ -911,6 +922,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.bigidx = d->bigidx;
         tp.nbig = use_bvh ? d->nbig : 0;
         tp.pmask = use_pmask ? d->pmask : nullptr;
+        tp.bvh_flags = bvh_flags;
+        tp.bvh_stack_limit = (int32_t)d->opt_bvh_stack;
         if (c == 0 && use_pmask) HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel; geometry may differ per call)
         // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
         const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
@@ -936,7 +949,19 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     }
     fb->version++;
     if (stats) stats->version++;
-    return event_end(d, ev);
+    if ((rc = event_end(d, ev))) return rc;
+    if (use_bvh) {
+        // The reference's brute force cannot skip a triangle (GenerateColors.cl:137-154); a search through the hierarchy
+        // that was cut short could -- so that is never silent: the kernels raise a sticky flag and the render FAILS.
+        // (One host synchronisation per LBVH render; such a render runs for milliseconds to seconds.)
+        unsigned int flags = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, bvh_flags, sizeof flags, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        if (flags != 0)
+            return fail(PT_ERR_TRAVERSAL, "LBVH search cut short (%s%s%s): the framebuffer of this render is not valid",
+                        (flags & 1u) ? "stack capacity" : "", (flags & 3u) == 3u ? ", " : "", (flags & 2u) ? "step budget" : "");
+    }
+    return PT_OK;
 }
 
 static int flush_pending(pt_device_s* d)

@@ -93,15 +93,27 @@ PTOR_INLINE v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b
 PTOR_INLINE v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
 PTOR_INLINE v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
 
+/* PTOR_NO_FMA_CONVENTION (oracle/Makefile: libptoracle_nofma.so, tests only, never the parity oracle): dot and cross
+ * as an OpenCL compiler WITHOUT fused multiply-add would evaluate the built-ins -- every product and sum rounded.  The
+ * distance between the two conventions' images is the honest tolerance against "any conforming OpenCL implementation"
+ * (tests/test_f64_model.py). */
 PTOR_INLINE float v3_dot(v3 a, v3 b)
 {
+#ifdef PTOR_NO_FMA_CONVENTION
+    return (a.x * b.x + a.y * b.y) + a.z * b.z;
+#else
     return ptor_fma(a.z, b.z, ptor_fma(a.y, b.y, a.x * b.x));
+#endif
 }
 PTOR_INLINE v3 v3_cross(v3 a, v3 b)
 {
+#ifdef PTOR_NO_FMA_CONVENTION
+    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+#else
     return v3_make(ptor_fma(a.y, b.z, -(a.z * b.y)),
                    ptor_fma(a.z, b.x, -(a.x * b.z)),
                    ptor_fma(a.x, b.y, -(a.y * b.x)));
+#endif
 }
 PTOR_INLINE v3 v3_normalize(v3 a)
 {
@@ -426,9 +438,11 @@ PTOR_INLINE v3 ptor_brdf(v3 wo, v3* wi, float* pdf, v3 normal, const ptor_materi
 }
 
 /* ------------------------------------------------------------------ path loop (:223-261) */
+/* hit_log (may be NULL; max_bounces + 1 ints, preset to -3 by the caller): the triangle hit at each bounce, then ONE end
+ * marker: -1 = the ray missed (:233), -2 = pdf <= 0 (:251); a path that uses all its bounces leaves the preset -3 */
 PTOR_INLINE v3 ptor_trace_rays(ptor_ray* r, const ptor_triangle* tris, int ntri,
                                const ptor_material* mats, uint32_t* seed, int max_bounces,
-                               ptor_stats* st)
+                               ptor_stats* st, int* hit_log)
 {
     v3 radiance = v3_make(0.0f, 0.0f, 0.0f);
     v3 mask = v3_make(1.0f, 1.0f, 1.0f);
@@ -441,8 +455,10 @@ PTOR_INLINE v3 ptor_trace_rays(ptor_ray* r, const ptor_triangle* tris, int ntri,
             radiance = v3_add(radiance, v3_scale(mask, bg));
             st->miss++;
             ended = 1;
+            if (hit_log) hit_log[i] = -1;
             break;
         }
+        if (hit_log) hit_log[i] = rec.tri;
         const ptor_material* material = &mats[tris[rec.tri].id];
         v3 em = v3_make(material->emissive[0], material->emissive[1], material->emissive[2]);
         radiance.x = radiance.x + mask.x * em.x * 3.0f;
@@ -456,7 +472,7 @@ PTOR_INLINE v3 ptor_trace_rays(ptor_ray* r, const ptor_triangle* tris, int ntri,
         float pdf = 0.0f;
         v3 color = ptor_brdf(wo, &wi, &pdf, n, material, seed, st);
 
-        if (pdf <= 0.0f) { st->term_pdf++; ended = 1; break; }
+        if (pdf <= 0.0f) { st->term_pdf++; ended = 1; if (hit_log) hit_log[i + 1] = -2; break; }
 
         float d = v3_dot(wi, n);
         mask.x = mask.x * (color.x * d / pdf);
@@ -479,7 +495,7 @@ PTOR_INLINE void ptor_sample_pixel(const ptor_triangle* tris, int ntri, const pt
     const int gj = gid / W;
     uint32_t seed = (uint32_t)gid + ptor_hash_u32((uint32_t)frame);
     ptor_ray r = ptor_generate_ray(gi, gj, W, H, &seed);
-    v3 c = ptor_trace_rays(&r, tris, ntri, mats, &seed, max_bounces, st);
+    v3 c = ptor_trace_rays(&r, tris, ntri, mats, &seed, max_bounces, st, 0);
     st->samples++;
     const float inv_gamma = 1.0f / PTOR_GAMMA;
     if (frame == 0) {
@@ -632,8 +648,26 @@ void ptor_kat_radiance(const void* tris, int ntri, const void* mats, int gid, in
     uint32_t seed = (uint32_t)gid + ptor_hash_u32((uint32_t)frame);
     ptor_ray r = ptor_generate_ray(gid % W, gid / W, W, H, &seed);
     v3 c = ptor_trace_rays(&r, (const ptor_triangle*)tris, ntri, (const ptor_material*)mats, &seed,
-                           max_bounces, &st);
+                           max_bounces, &st, 0);
     out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+
+/* n paths (gid[k], frame[k]): radiance (no accumulation) and the triangle hit at every bounce.  hits = n x (max_bounces + 1)
+ * ints, preset to -3 here: the hit triangles, then -1 (miss) or -2 (pdf <= 0), -3 beyond the path's end */
+PTOR_CLONES
+void ptor_kat_paths(const void* tris, int ntri, const void* mats, const int32_t* gid, const int32_t* frame, int64_t n, int W, int H,
+                    int max_bounces, float* out3, int32_t* hits)
+{
+    ptor_stats st;
+    memset(&st, 0, sizeof st);
+    for (int64_t k = 0; k < n; ++k) {
+        int* log = hits + k * (max_bounces + 1);
+        for (int b = 0; b <= max_bounces; ++b) log[b] = -3;
+        uint32_t seed = (uint32_t)gid[k] + ptor_hash_u32((uint32_t)frame[k]);
+        ptor_ray r = ptor_generate_ray(gid[k] % W, gid[k] / W, W, H, &seed);
+        v3 c = ptor_trace_rays(&r, (const ptor_triangle*)tris, ntri, (const ptor_material*)mats, &seed, max_bounces, &st, log);
+        out3[3 * k] = c.x; out3[3 * k + 1] = c.y; out3[3 * k + 2] = c.z;
+    }
 }
 
 int ptor_stats_words(void) { return (int)(sizeof(ptor_stats) / 8); }

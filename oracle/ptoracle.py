@@ -30,14 +30,33 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(variant: str = ""):
+    """The oracle ("") or the same restatement under another arithmetic convention ("nofma": dot / cross without fused
+    multiply-add; tests only -- see oracle/Makefile)."""
     global _lib
+    if variant:
+        if variant not in _libs:
+            path = os.path.join(_HERE, "libptoracle_%s.so" % variant)
+            if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "pt_oracle.c")):
+                subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
+            L = ctypes.CDLL(path)
+            _bind(L)
+            _libs[variant] = L
+        return _libs[variant]
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
         L = ctypes.CDLL(_LIB_PATH)
+        _bind(L)
+        _lib = L
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.ptor_kat_hash.restype = ctypes.c_uint32
         L.ptor_kat_hash.argtypes = [ctypes.c_uint32]
         L.ptor_kat_random.restype = ctypes.c_float
@@ -51,8 +70,6 @@ def lib():
             ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
         ]
         assert L.ptor_stats_words() == len(STATS_FIELDS)
-        _lib = L
-    return _lib
 
 
 def _ptr(a: np.ndarray):
@@ -114,8 +131,23 @@ def radiance(tris, mats, gid, W, H, frame, max_bounces=16):
     return out
 
 
+def paths(tris, mats, gids, frames, W, H, max_bounces=16, variant=""):
+    """Radiance (n, 3) and hit sequences (n, max_bounces + 1) of the paths (gid[k], frame[k]); a sequence is the triangle
+    hit at every bounce, then -1 (missed) or -2 (pdf <= 0), -3 beyond the path's end."""
+    tris = np.ascontiguousarray(tris)
+    mats = np.ascontiguousarray(mats)
+    gids = np.ascontiguousarray(gids, np.int32)
+    frames = np.ascontiguousarray(frames, np.int32)
+    assert gids.shape == frames.shape and gids.ndim == 1
+    rad = np.zeros((gids.size, 3), np.float32)
+    hits = np.zeros((gids.size, max_bounces + 1), np.int32)
+    lib(variant).ptor_kat_paths(_ptr(tris), len(tris), _ptr(mats), _ptr(gids), _ptr(frames), ctypes.c_int64(gids.size), W, H,
+                                max_bounces, _ptr(rad), _ptr(hits))
+    return rad, hits
+
+
 def render(tris, mats, W, H, frames, *, frame_begin=0, max_bounces=16, fb=None,
-           gid_begin=0, gid_count=None, nthreads=None, want_stats=False):
+           gid_begin=0, gid_count=None, nthreads=None, want_stats=False, variant=""):
     """Run frames [frame_begin, frame_begin+frames) over a gid range.
 
     Returns the (H*W, 4) float32 framebuffer (the one passed in, updated in place, or a new
@@ -131,7 +163,7 @@ def render(tris, mats, W, H, frames, *, frame_begin=0, max_bounces=16, fb=None,
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     st = np.zeros(len(STATS_FIELDS), np.uint64)
-    rc = lib().ptor_render(_ptr(tris), len(tris), _ptr(mats), len(mats), _ptr(fb), W, H, frame_begin,
+    rc = lib(variant).ptor_render(_ptr(tris), len(tris), _ptr(mats), len(mats), _ptr(fb), W, H, frame_begin,
                            frames, max_bounces, gid_begin, gid_count, nthreads, _ptr(st))
     if rc != 0:
         raise ValueError("ptor_render rejected the arguments (rc=%d)" % rc)
