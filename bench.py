@@ -46,7 +46,7 @@ BYTES_PER_SAMPLE = 32.0         # 16 B read + 16 B write of one float4 pixel (Ge
 # LBVH search (configs[4]): per eight-child node entered, eight slab tests (6 FMA = 12 flop, 6 min/max, 1 compare = 19
 # flop each) + 9 for the node's frame; per triangle tested the reference's full test (52, reach_t) -- DESIGN.md S4
 F_BVH_NODE, F_BVH_TRI = 161.0, 52.0
-B_BVH_NODE, B_BVH_TRI = 80.0, 48.0   # the 80 bytes read of a node's 128-byte slot per node entered, one 48-byte leaf record per triangle tested
+B_BVH_NODE, B_BVH_TRI = 64.0, 48.0   # one 64-byte node record per node entered, 48 bytes of a 64-byte leaf record per triangle tested
 
 
 def pmc_traffic():
@@ -122,24 +122,41 @@ def cpu_baseline(tris, mats, depth, target_seconds=12.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150, help="timed renders (default: a timed region of about 5 s)")
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="the BASELINE.json workload, by its index in `configs`: 1 = cornellbox 512^2 x 64 spp depth 2; 2 = cornellbox 1024^2 x 256 spp "
+                         "(the headline, default); 3 = cornellbox 2048^2 x 1024 spp (BASELINE: 8 GPUs + gather); 4 = 10^6-triangle soup 1024^2 x 256 spp "
+                         "(BASELINE: 8 GPUs).  --width/--height/--spp/--depth/--soup override single values")
+    ap.add_argument("--steps", type=int, default=None, help="timed renders (default: a timed region of a few seconds for the chosen workload)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--stripe-rows", type=int, default=4,
                     help="rows per image stripe of the N-rank split (4: the ranks' shares of configs[2] are equal to 1 %%; 16: 2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] / configs[4] legs of extra.configs")
     ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 4 packed")
     ap.add_argument("--accel", type=int, default=0, help="PT_OPT_ACCEL: 0 auto (LBVH from 512 triangles), 1 brute force, 2 LBVH")
-    ap.add_argument("--soup", type=int, default=0, help="render the synthetic N-triangle soup of BASELINE configs[4] (Cornell box + "
+    ap.add_argument("--soup", type=int, default=None, help="render the synthetic N-triangle soup of BASELINE configs[4] (Cornell box + "
                     "N-36 small triangles) instead of cornellbox.bin (no cpu_baseline: the oracle is O(N) per ray)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > visible GPUs: ranks share devices (rank %% device_count) and gather over gloo through the host. "
                          "Exercises the N-rank code path on a smaller box; the line says so and is no scaling measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # the named workloads: (width, height, spp, depth, soup triangles, default steps, default warm-up)
+    table = {1: (512, 512, 64, 2, 0, 400, 5), 2: (1024, 1024, 256, 16, 0, 150, 5), 3: (2048, 2048, 1024, 16, 0, 8, 1),
+             4: (1024, 1024, 256, 16, 1_000_000, 3, 1)}
+    w, h, spp, depth, soup, steps, warm = table[args.config]
+    args.named = all(v is None for v in (args.width, args.height, args.spp, args.depth, args.soup))  # exactly BASELINE's configs[k]
+    args.width = w if args.width is None else args.width
+    args.height = h if args.height is None else args.height
+    args.spp = spp if args.spp is None else args.spp
+    args.depth = depth if args.depth is None else args.depth
+    args.soup = soup if args.soup is None else args.soup
+    args.steps = steps if args.steps is None else args.steps
+    args.warmup = warm if args.warmup is None else args.warmup
+    return args
 
 
 # ---------------------------------------------------------------------------------------------
@@ -156,15 +173,52 @@ def spawn_ranks(args) -> int:
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode("utf-8", "replace"))
+                                      stdout=subprocess.PIPE if r == 0 else None))   # (other ranks print nothing on stdout; stderr is inherited)
+    # supervise ALL ranks: a rank that dies at start-up would leave the others waiting in the rendezvous or a collective
+    # until the backend's timeout.  On the first failure the rest are stopped and that rank's code is returned.
+    out_chunks = []
+    import selectors
+
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    failed = None
+    open_out = True
+    while True:
+        if open_out:
+            for key, _ in sel.select(timeout=0.2):
+                chunk = os.read(key.fileobj.fileno(), 65536)
+                if chunk:
+                    out_chunks.append(chunk)
+                else:
+                    sel.unregister(key.fileobj)
+                    open_out = False
+        else:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed is None:
+            failed = bad
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        if all(c is not None for c in codes) and not open_out:
+            break
+        if all(c is not None for c in codes) and open_out:
+            # drain what rank 0 left in the pipe
+            rest = procs[0].stdout.read()
+            if rest:
+                out_chunks.append(rest)
+            break
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    sys.stdout.write(b"".join(out_chunks).decode("utf-8", "replace"))
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %d" % rc for rc in bad))
-        return max(abs(c) for _, c in bad) or 1
+    if failed:
+        sys.stderr.write("bench.py: rank(s) failed first: %s; the other ranks were stopped\n" % ", ".join("rank %d rc %d" % rc for rc in failed))
+        return max(abs(c) for _, c in failed) or 1
     return 0
 
 
@@ -266,10 +320,13 @@ def main():
     rehearsal = world > ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+
+        tmo = datetime.timedelta(seconds=180)   # a missing peer fails the rendezvous in minutes, not the backend's default half hour
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_idx))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_idx), timeout=tmo)
 
     from oclpathtracer_amd import adl, scene, shim
     from oclpathtracer_amd.distributed import StripeImage
@@ -339,7 +396,8 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (cornellbox.bin scene, seeded per-pixel RNG of the reference)",
-            "config": {"workload": "cornellbox.bin %dx%d, %d spp, depth %d, full path (BASELINE configs[2])" % (W, H, spp, depth),
+            "config": {"workload": ("BASELINE configs[%d]: " % args.config if args.named else "") +
+                                   "cornellbox.bin %dx%d, %d spp, depth %d%s" % (W, H, spp, depth, ", full path" if depth >= 16 else ""),
                        "sharding": "%d-row image stripes round-robin over %d rank(s), RCCL gather to rank 0%s" % (
                            args.stripe_rows, world, " (two framebuffers per rank: the gather of a step runs beside the next step's render)" if world > 1 else ""),
                        "rays_per_sample": total_rays / total_samples, "timed_region_s": dt},
@@ -355,8 +413,8 @@ def main():
         cpu = None
         if args.soup:
             out["metric"] = "Msamples/sec (pixels x spp / s), %d-triangle soup %dx%d" % (len(tris), W, H)
-            out["config"]["workload"] = "soup of %d triangles (BASELINE configs[4] generator) %dx%d, %d spp, depth %d, accel %d" % (
-                len(tris), W, H, spp, depth, args.accel)
+            out["config"]["workload"] = ("BASELINE configs[4]: " if args.named and args.config == 4 else "") + \
+                "soup of %d triangles (BASELINE configs[4] generator) %dx%d, %d spp, depth %d, accel %d" % (len(tris), W, H, spp, depth, args.accel)
             if args.accel != 1 and world == 1:
                 tally = bvh_tallies(dev, lib, shim, tris, mats, W, H, depth)
                 out["roofline"], out["roofline_valu"] = soup_roofline(tally, rank_rays, rank_samples, avg_ms)

@@ -16,8 +16,8 @@
 // hipcub radix sort, one thread per internal node finds its range and split, bottom-up box refit
 // with one atomic flag per internal node (fp32 boxes of both children in the binary node).  The binary
 // tree is then collapsed three levels at a time into the eight-child nodes the trace kernel walks
-// (PtBvh8Node, pt_kernels.h: 80 bytes in a 128-byte slot, 8-bit boxes in the node's frame, children
-// stored consecutively, slots assigned by octant); WHICH binary nodes become eight-child nodes is chosen by dynamic
+// (PtBvh8Node, pt_kernels.h: 64 bytes, 8-bit boxes in the node's frame, 16-bit origin on a scene grid, children
+// -- nodes and leaf records alike -- stored consecutively, slots assigned by octant); WHICH binary nodes become eight-child nodes is chosen by dynamic
 // programming over the subtree costs (pt_bvh8_cost_kernel, pt_bvh8_topdown_kernel).
 #include "pt_kernels.h"
 
@@ -86,6 +86,25 @@ __global__ void pt_bvh_threshold_kernel(unsigned* __restrict__ bounds)
     for (int k = 0; k < 3; ++k) ext = fmaxf(ext, pt_unordered(bounds[3 + k]) - pt_unordered(bounds[k]));
     bounds[8] = __float_as_uint(ext > 0.0f ? ext / PT_BVH_BIG_DIV : __builtin_inff());  // (an empty / degenerate scene: no split)
     bounds[9] = 0u;
+}
+
+// the grid of the nodes' 16-bit origins (PtBvhGrid): it must reach below every box a node can hold -- triangle boxes grown
+// by eps (pt_bvh_refit_kernel) -- and its 65 536 positions per axis must span them; steps are powers of two
+__global__ void pt_bvh_grid_kernel(const unsigned* __restrict__ bounds, PtBvhGrid* __restrict__ grid)
+{
+    const float eps = PT_BVH_EPS * pt_unordered(bounds[6]) + 1e-30f;
+    for (int a = 0; a < 3; ++a) {
+        float lo = pt_unordered(bounds[a]), hi = pt_unordered(bounds[3 + a]);
+        if (!(lo <= hi)) { lo = 0.0f; hi = 0.0f; }  // no finite triangle at all
+        const float gmin = lo - 2.0f * eps;
+        const float ext = (hi - lo) + 4.0f * eps;
+        int e2 = -126;
+        if (ext > 0.0f) (void)frexpf(ext / 65535.0f, &e2);  // ext / 65535 = m 2^e2 with m < 1: 65535 steps of 2^e2 cover ext
+        int be = e2 + 127;
+        be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        grid->gmin[a] = gmin;
+        grid->gstep[a] = __uint_as_float((unsigned)be << 23);
+    }
 }
 
 __global__ void pt_bvh_big_collect_kernel(const PtRawTriangle* __restrict__ raw, int ntri, unsigned* __restrict__ bounds,
@@ -268,47 +287,45 @@ __device__ void pt_bvh8_slots(PtGather8& g)
     }
 }
 
-// the node of the gathered children (slots assigned), its leaf children's records at ltris[tri_base ...]
-__device__ void pt_bvh8_write(const PtGather8& g, unsigned child_base, unsigned tri_base, const unsigned long long* __restrict__ keys,
-                              const PtPrepTriangle* __restrict__ prep, PtBvh8Node* __restrict__ dst, PtLeafTri* __restrict__ ltris)
+// the node of the gathered children (slots assigned) into recs[self]; its children are records base, base + 1, ... in slot
+// order: the leaf children's records are written here, the node children's by the threads that take them off the queue
+__device__ void pt_bvh8_write(const PtGather8& g, unsigned self, unsigned base, const unsigned long long* __restrict__ keys,
+                              const PtPrepTriangle* __restrict__ prep, const PtBvhGrid* __restrict__ grid, PtBvh8Node* __restrict__ recs)
 {
     PtBvh8Node o;
-    o.child_base = child_base;
-    o.tri_base = tri_base;
+    o.base = base;
+    o.pad = 0;
     unsigned imask = 0u, lmask = 0u;
     for (int k = 0; k < g.m; ++k) {
         if (g.link[k] & 0x80000000u) lmask |= 1u << g.slot[k];
         else imask |= 1u << g.slot[k];
     }
-    o.lmask = lmask;
-    o.pad0 = 0u;
-    for (unsigned k = 0; k < sizeof o.pad / sizeof o.pad[0]; ++k) o.pad[k] = 0u;
-    // the leaf children's records, in slot order
-    {
-        unsigned rank = 0u;
-        for (int sl = 0; sl < 8; ++sl)
-            for (int k = 0; k < g.m; ++k)
-                if (g.slot[k] == sl && (g.link[k] & 0x80000000u)) {
-                    const unsigned tri = (unsigned)keys[g.link[k] & 0x7fffffffu];
-                    const PtPrepTriangle t = prep[tri];
-                    PtLeafTri r;
-                    for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
-                    r.index = tri;
-                    for (unsigned z = 0; z < sizeof r.pad / sizeof r.pad[0]; ++z) r.pad[z] = 0.0f;
-                    if (rank == 0u) {  // the first leaf's record also rides in the node's own line (the trace kernel reads it there)
-                        static_assert(sizeof o.pad >= 48, "room for one leaf record");
-                        const uint32_t* w = reinterpret_cast<const uint32_t*>(&r);
-                        for (int z = 0; z < 12; ++z) o.pad[z] = w[z];
-                    }
-                    ltris[o.tri_base + rank++] = r;
-                }
-    }
-    unsigned ex[3] = { 1u, 1u, 1u };
+    o.imask = (uint8_t)imask;
+    o.lmask = (uint8_t)lmask;
+    // the leaf children's records
+    for (int k = 0; k < g.m; ++k)
+        if (g.link[k] & 0x80000000u) {
+            const unsigned rank = (unsigned)__popc((imask | lmask) & ((1u << g.slot[k]) - 1u));
+            const unsigned tri = (unsigned)keys[g.link[k] & 0x7fffffffu];
+            const PtPrepTriangle t = prep[tri];
+            PtLeafTri r;
+            for (int a = 0; a < 3; ++a) { r.p1[a] = t.p1[a]; r.e1[a] = t.e1[a]; r.e2[a] = t.e2[a]; }
+            r.index = tri;
+            for (unsigned z = 0; z < sizeof r.pad / sizeof r.pad[0]; ++z) r.pad[z] = 0.0f;
+            *reinterpret_cast<PtLeafTri*>(recs + base + rank) = r;
+        }
     for (int a = 0; a < 3; ++a) {
-        float org = 3.0e38f, top = -3.0e38f;
-        for (int k = 0; k < g.m; ++k) { org = fminf(org, g.lo[k][a]); top = fmaxf(top, g.hi[k][a]); }
-        if (!(org <= top)) { org = 0.0f; top = 0.0f; }
-        o.origin[a] = org;
+        float lo = 3.0e38f, top = -3.0e38f;
+        for (int k = 0; k < g.m; ++k) { lo = fminf(lo, g.lo[k][a]); top = fmaxf(top, g.hi[k][a]); }
+        if (!(lo <= top)) { lo = grid->gmin[a]; top = lo; }
+        // the origin: the grid position at or below the children's lower corner, checked by decoding as the traversal does
+        const float gmin = grid->gmin[a], gstep = grid->gstep[a];
+        float fq = floorf((lo - gmin) / gstep);
+        fq = fminf(fmaxf(fq, 0.0f), 65535.0f);
+        unsigned q16 = (unsigned)fq;
+        while (q16 > 0u && pt_bvh_decode(q16, gstep, gmin) > lo) --q16;
+        const float org = pt_bvh_decode(q16, gstep, gmin);  // (<= lo: the grid starts 2 eps below every box)
+        o.org[a] = (uint16_t)q16;
         // smallest power of two `step` with decode(255) >= top; then every bound rounded outward and CHECKED by decoding
         int e2 = -126;
         const float ext = top - org;
@@ -317,7 +334,7 @@ __device__ void pt_bvh8_write(const PtGather8& g, unsigned child_base, unsigned 
         be = be < 1 ? 1 : (be > 254 ? 254 : be);
         for (;;) {
             const float step = __uint_as_float((unsigned)be << 23);
-            bool ok = true;
+            bool ok = org <= lo;
             for (int sl = 0; sl < 8; ++sl) { o.qlo[a][sl] = 255; o.qhi[a][sl] = 0; }  // an empty slot: inverted (and in neither mask)
             for (int k = 0; k < g.m && ok; ++k) {
                 float fl = floorf((g.lo[k][a] - org) / step), fh = ceilf((g.hi[k][a] - org) / step);
@@ -333,10 +350,9 @@ __device__ void pt_bvh8_write(const PtGather8& g, unsigned child_base, unsigned 
             if (ok || be >= 254) break;  // (be = 254 always suffices for finite boxes: 255 x 2^127 spans binary32)
             ++be;
         }
-        ex[a] = (unsigned)be;
+        o.ex[a] = (uint8_t)be;
     }
-    o.meta = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
-    *dst = o;
+    recs[self] = o;
 }
 
 
@@ -418,11 +434,11 @@ __global__ void pt_bvh8_cost_kernel(const PtBvhNode* __restrict__ nodes, const i
 
 struct PtWork8 { int node; int idx; };  // binary node, index of the eight-child node it becomes
 
-// counters[0] = next free node index, counters[1] = next free leaf record, in_count / out_count: the two frontiers' sizes
+// counters[0] = next free record, in_count / out_count: the two frontiers' sizes
 __global__ void pt_bvh8_topdown_kernel(const PtBvhNode* __restrict__ nodes, const PtCost8* __restrict__ tab, const PtWork8* __restrict__ in,
                                        const unsigned* __restrict__ in_count, PtWork8* __restrict__ outq, unsigned* __restrict__ out_count,
                                        unsigned* __restrict__ counters, const unsigned long long* __restrict__ keys,
-                                       const PtPrepTriangle* __restrict__ prep, PtBvh8Node* __restrict__ out, PtLeafTri* __restrict__ ltris)
+                                       const PtPrepTriangle* __restrict__ prep, const PtBvhGrid* __restrict__ grid, PtBvh8Node* __restrict__ recs)
 {
     const unsigned total = *in_count;
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
@@ -472,23 +488,19 @@ __global__ void pt_bvh8_topdown_kernel(const PtBvhNode* __restrict__ nodes, cons
             }
         }
         pt_bvh8_slots(g);
-        unsigned n_int = 0u, n_leaf = 0u;
-        for (int k = 0; k < g.m; ++k) { if (g.link[k] & 0x80000000u) ++n_leaf; else ++n_int; }
-        const unsigned cbase = n_int ? atomicAdd(&counters[0], n_int) : 0u;
-        const unsigned lbase = n_leaf ? atomicAdd(&counters[1], n_leaf) : 0u;
-        pt_bvh8_write(g, cbase, lbase, keys, prep, out + wk.idx, ltris);
+        unsigned n_int = 0u, cmask = 0u;
+        for (int k = 0; k < g.m; ++k) { cmask |= 1u << g.slot[k]; if (!(g.link[k] & 0x80000000u)) ++n_int; }
+        const unsigned base = g.m ? atomicAdd(&counters[0], (unsigned)g.m) : 0u;
+        pt_bvh8_write(g, (unsigned)wk.idx, base, keys, prep, grid, recs);
         if (n_int) {
-            const unsigned qbase = atomicAdd(out_count, n_int);
-            unsigned rank = 0u;
-            for (int sl = 0; sl < 8; ++sl)
-                for (int k = 0; k < g.m; ++k)
-                    if (g.slot[k] == sl && !(g.link[k] & 0x80000000u)) {
-                        PtWork8 nw;
-                        nw.node = (int)g.link[k];
-                        nw.idx = (int)(cbase + rank);
-                        outq[qbase + rank] = nw;
-                        ++rank;
-                    }
+            unsigned qpos = atomicAdd(out_count, n_int);
+            for (int k = 0; k < g.m; ++k)
+                if (!(g.link[k] & 0x80000000u)) {
+                    PtWork8 nw;
+                    nw.node = (int)g.link[k];
+                    nw.idx = (int)(base + (unsigned)__popc(cmask & ((1u << g.slot[k]) - 1u)));
+                    outq[qpos++] = nw;
+                }
         }
     }
 }
@@ -497,14 +509,12 @@ __global__ void pt_bvh8_topdown_init_kernel(PtWork8* q, unsigned* counts, unsign
 {
     q[0].node = 0; q[0].idx = 0;
     counts[0] = 1u; counts[1] = 0u;
-    counters[0] = 1u;  // node 0 is the root
+    counters[0] = 1u;  // record 0 is the root
     counters[1] = 0u;
 }
 __global__ void pt_bvh8_zero_kernel(unsigned* p) { *p = 0u; }
 
 }  // namespace
-
-size_t ptk_bvh_node_count(int ntri) { return ntri > 1 ? (size_t)ptk_bvh_leaf_count(ntri) - 1 : 0; }
 
 size_t ptk_bvh_temp_bytes(int ntri)
 {
@@ -519,7 +529,7 @@ size_t ptk_bvh_temp_bytes(int ntri)
 
 // work: 36 n bytes of cost tables, two frontiers of 8 n bytes, counts and counters
 static hipError_t pt_bvh8_build_sah(const PtBvhNode* nodes, const int* parent, int nleaves, int* flags, const unsigned long long* sorted,
-                                    const PtPrepTriangle* prep, PtBvh8Node* nodes8, PtLeafTri* ltris, char* work, hipStream_t s)
+                                    const PtPrepTriangle* prep, const PtBvhGrid* grid, PtBvh8Node* recs, char* work, hipStream_t s)
 {
     const size_t n = (size_t)nleaves;
     work = (char*)(((uintptr_t)work + 15) & ~(uintptr_t)15);
@@ -540,13 +550,13 @@ static hipError_t pt_bvh8_build_sah(const PtBvhNode* nodes, const int* parent, i
         PtWork8* outq = (lvl & 1) ? q0 : q1;
         hipLaunchKernelGGL(pt_bvh8_zero_kernel, dim3(1), dim3(1), 0, s, counts + ((lvl + 1) & 1));
         hipLaunchKernelGGL(pt_bvh8_topdown_kernel, tgrd, blk, 0, s, nodes, tab, in, counts + (lvl & 1), outq, counts + ((lvl + 1) & 1), counters, sorted,
-                           prep, nodes8, ltris);
+                           prep, grid, recs);
     }
     return hipGetLastError();
 }
 
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes8, PtLeafTri* ltris,
-                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s)
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* recs,
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
@@ -569,6 +579,7 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     const dim3 blk(256), grd((ntri + 255) / 256);
     hipLaunchKernelGGL(pt_bvh_bounds_kernel, grd, blk, 0, s, raw, ntri, bounds);
     hipLaunchKernelGGL(pt_bvh_threshold_kernel, dim3(1), dim3(1), 0, s, bounds);
+    hipLaunchKernelGGL(pt_bvh_grid_kernel, dim3(1), dim3(1), 0, s, bounds, grid_dev);
     hipLaunchKernelGGL(pt_bvh_big_collect_kernel, grd, blk, 0, s, raw, ntri, bounds, bigidx);
     hipLaunchKernelGGL(pt_bvh_big_finish_kernel, dim3(1), dim3(1), 0, s, bounds, bigidx, prep, bigtab, nbig_dev);
     hipLaunchKernelGGL(pt_bvh_keys_kernel, grd, blk, 0, s, raw, ntri, bounds, keys);
@@ -578,5 +589,5 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, sorted, nleaves, nodes, parent, right_child);
     hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, nleaves, bounds, nodes, parent, right_child, flags);
     // (the sort is done with its workspace by now: the collapse's tables live at the end of `temp`)
-    return pt_bvh8_build_sah(nodes, parent, nleaves, flags, sorted, prep, nodes8, ltris, (char*)temp + temp_bytes - (36 * n + 16 * n + 256), s);
+    return pt_bvh8_build_sah(nodes, parent, nleaves, flags, sorted, prep, grid_dev, recs, (char*)temp + temp_bytes - (36 * n + 16 * n + 256), s);
 }

@@ -34,15 +34,18 @@ struct PtBvhNode {
 };
 static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 
-// The node the trace kernel walks: EIGHT children in 80 bytes of a 128-byte aligned slot, one cache line, one request
-// (tools/ubench_gather, profiles/r02/ubench_gather.txt: dependent random reads of a 70 MB table run at 75 G/s for 64-byte
-// records and at 86 G/s for aligned 128-byte records; the search is bound by its line requests and by VALU issue in
-// about equal parts, so a node holds as many children as a line allows and costs as few instructions as possible --
-// after Ylitie, Karras, Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017):
+// The node the trace kernel walks: EIGHT children in 64 bytes -- one 64-byte sector of a cache line, four 16-byte loads
+// (after Ylitie, Karras, Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017).  Round 3
+// measured what the search is bound by (profiles/r03/lbvh_bottlenecks.txt): every 16-byte load of a wave whose 64 lanes
+// read 64 different lines costs the CU's texture-address path 64 cycles -- one MORE such load per node visit cost 8.7 % --
+// and the L2's miss path moves sectors, not requests (tools/ubench_gather: 64-byte records 111 G/s, 128-byte records 86 G/s).
+// Round 2's node was 80 bytes in a 128-byte slot (five loads, both sectors); this one is 64 (four loads, one sector, two
+// nodes per line: siblings lie next to each other and a ray that enters one often enters the other):
 //   * which binary nodes of the radix tree become nodes here, and which of their descendants their (at most eight)
 //     children are, is chosen by dynamic programming over surface-area costs (pt_bvh.hip);
-//   * children that are nodes are stored CONSECUTIVELY (child_base + rank among the node children, in slot order),
-//     children that are leaves have their 48-byte records consecutively in the leaf array (tri_base + rank): no links;
+//   * nodes and leaf records are 64-byte RECORDS of ONE array; the children of a node -- nodes and leaves alike -- are
+//     stored consecutively in slot order from `base`: the child in slot s is record base + popcount((imask | lmask) &
+//     ((1 << s) - 1)): no links, one base;
 //   * a child sits in the slot whose three bits say on which side of the node's centre it lies (x = bit 0, y = bit 1,
 //     z = bit 2; greedy assignment), so "slot XOR (ray direction's octant)" orders the children front to back for
 //     every ray without a sort;
@@ -50,32 +53,32 @@ static_assert(sizeof(PtBvhNode) == 64, "bvh node layout");
 //     power-of-two step per axis), rounded OUTWARD and verified at build time by decoding (fma(q, step, origin) contains
 //     the fp32 box); stored per axis (qlo[axis][slot], qhi[axis][slot]) so the ray's direction signs pick the near and
 //     far planes of all eight children with four selects per axis; an empty slot holds an inverted box (255, 0) AND is
-//     missing from both masks.
-struct alignas(128) PtBvh8Node {
-    float origin[3];
-    uint32_t meta;        // step exponents (biased as in binary32) x | y << 8 | z << 16 | imask << 24
-    uint32_t child_base;  // the child in slot s (imask bit s set) is node child_base + popcount(imask & ((1 << s) - 1))
-    uint32_t tri_base;    // the leaf in slot s (lmask bit s set) is record tri_base + popcount(lmask & ((1 << s) - 1))
-    uint32_t lmask;       // slots that hold leaves (low 8 bits); imask (meta >> 24): slots that hold nodes
-    uint32_t pad0;
+//     missing from both masks;
+//   * the origin itself is 16 bits per axis on a grid over the scene (PtBvhGrid: origin = fma(org, grid step, grid min),
+//     rounded DOWN and checked by decoding with the very expression the traversal uses; the boxes are quantised against
+//     the decoded origin, so nothing is lost but up to one grid step -- 1 / 65 535 of the scene -- of the 8-bit range).
+struct alignas(64) PtBvh8Node {
+    uint16_t org[3];      // origin on the scene grid
+    uint8_t ex[3];        // step exponents (biased as in binary32)
+    uint8_t imask;        // slots that hold nodes
+    uint8_t lmask;        // slots that hold leaves
+    uint8_t pad;
+    uint32_t base;        // record index of the first child
     uint8_t qlo[3][8];    // [axis][slot]
     uint8_t qhi[3][8];
-    uint32_t pad[12];     // a copy of the first leaf child's record (PtLeafTri's first 48 bytes), zero without leaf children
 };
-static_assert(sizeof(PtBvh8Node) == 128, "bvh node layout");
+static_assert(sizeof(PtBvh8Node) == 64, "bvh node layout");
+struct PtBvhGrid { float gmin[3], gstep[3]; };  // the origins' grid (steps are powers of two: org * gstep is exact)
 
-// A LEAF of the hierarchy is ONE triangle: a compact 48-byte record, three 16-byte loads.  (Leaves of four
+// A LEAF of the hierarchy is ONE triangle: a 64-byte record of the same array, three 16-byte loads.  (Leaves of four
 // consecutive triangles of the Morton order were measured in round 2: the 10^6-triangle soup's leaf boxes grow 9x in
 // cross-section, 184 instead of 5.4 triangle tests per ray, 35 instead of 86 Msamples/s.)
-#ifndef PT_LEAF_STRIDE
-#define PT_LEAF_STRIDE 64  // (48 bytes of data: a 48-byte stride lets a quarter of the records straddle two 128-byte lines: 202 against 209 Msamples/s)
-#endif
-struct alignas(PT_LEAF_STRIDE == 64 ? 64 : 16) PtLeafTri {
+struct alignas(64) PtLeafTri {
     float p1[3], e1[3], e2[3];  // as in PtPrepTriangle
     uint32_t index;             // the triangle's index in the caller's buffer (ties in t go to the lowest)
-    float pad[PT_LEAF_STRIDE / 4 - 10];
+    float pad[6];
 };
-static_assert(sizeof(PtLeafTri) == PT_LEAF_STRIDE, "leaf record layout");
+static_assert(sizeof(PtLeafTri) == 64, "leaf record layout");
 
 #define PT_TRACE_BATCH 256u    // largest number of samples per work-queue grab of a wave (PtTraceParams::batch)
 #define PT_TRACE_THREADS 256   // 4 waves per workgroup (variant 1)
@@ -101,9 +104,10 @@ struct PtTraceParams {
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
     const float* p1tab;           // quad mode 3: packed pass-1 table, PT_P1_STRIDE floats per pair of quads
     float p1_lo, p1_hi;           // quad mode 3: bounds of the shared numerator for the first / second triangle
-    const PtBvh8Node* bvh;        // accel = BVH: eight-child nodes, root 0, every node's node children consecutive
-    const PtLeafTri* ltris;       // accel = BVH: the leaf records, every node's leaf children consecutive
-    int32_t bvh_leaves;           //              number of leaves; the hierarchy has at most bvh_leaves - 1 nodes
+    const PtBvh8Node* bvh;        // accel = BVH: the hierarchy's 64-byte records (nodes and leaves), root = record 0, every node's
+                                  //              children consecutive
+    int32_t bvh_records;          //              capacity of that array (2 x triangles): indices are checked against it
+    PtBvhGrid grid;               //              the grid of the nodes' 16-bit origins
     const PtPrepTriangle* bigtab; // accel = BVH: prepared records of the nbig triangles kept out of the hierarchy (brute-force searched)
     const int32_t* bigidx;        //              their triangle indices, ascending
     int32_t nbig;
@@ -141,15 +145,14 @@ hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s);
 // bvh: traverse p.bvh instead of the brute-force two-pass search
 // tally: (bvh only) the measurement variant that adds the search's work counters to p.stats[2..5]
 hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s);
-size_t ptk_bvh_node_count(int ntri);
+static inline size_t ptk_bvh_record_count(int ntri) { return 2 * (size_t)(ntri > 0 ? ntri : 0); }  // < ntri nodes + ntri leaves
 size_t ptk_bvh_temp_bytes(int ntri);
 // prep: the prepared records of the same triangles.  bigtab[PT_BVH_BIG_MAX] / bigidx[PT_BVH_BIG_MAX] / *nbig_dev (device memory)
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
-// nodes[ptk_bvh_leaf_count(ntri) - 1] and ltris[ntri] (device memory) receive the hierarchy the trace kernel walks
-hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* nodes, PtLeafTri* ltris,
-                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, void* temp, size_t temp_bytes, hipStream_t s);
-static inline int ptk_bvh_leaf_count(int ntri) { return ntri; }  // one triangle per leaf
+// recs[ptk_bvh_record_count(ntri)] (device memory) receives the hierarchy the trace kernel walks, *grid_dev its origin grid
+hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* recs,
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, void* temp, size_t temp_bytes, hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);

@@ -1344,10 +1344,10 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 // 34 %).  Here the search is a per-lane STATE that survives the shading phase: the wave steps all traversing lanes
 // together, and as soon as no more than PT_BVH_REFILL of them are still traversing, the finished lanes are shaded,
 // dead ones take new samples, and all of them start their next search while the stragglers simply keep theirs.
-//   * the hierarchy: eight-child nodes of 80 bytes in 128-byte slots (PtBvh8Node, pt_kernels.h; built by pt_bvh.hip),
-//     one line request per node.  The search runs at the rate its L2 misses are served at, with the vector ALUs ~90 %
-//     busy beside it (profiles/r02/pmc_soup_lbvh_cw8.txt), so a node is one line and the node step is built for few
-//     instructions: entry / exit distances are one
+//   * the hierarchy: eight-child nodes of 64 bytes (PtBvh8Node, pt_kernels.h; built by pt_bvh.hip): one sector, four
+//     16-byte loads.  Three things bound the search about equally (profiles/r03/lbvh_bottlenecks.txt): vector-ALU issue,
+//     the texture-address path (64 cycles for every load whose lanes read 64 different lines) and the L2's miss path; so a
+//     node is as small as eight children allow and the node step is built for few instructions: entry / exit distances are one
 //     FMA per plane straight from the quantised bytes, the ray's direction signs select the near and far planes of all
 //     eight children at once, the children's slots encode their octant so "slot XOR ray octant" is the front-to-back
 //     order (no sort), and the hits of a node travel as ONE stack entry (base index, hit mask) instead of one per child;
@@ -1469,14 +1469,13 @@ typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
 // the slot, initialised with the ray's incumbent (tmax, hidx), ends up holding the reference's winner whatever the order of
 // the tests.  A ray's tmax now shrinks a few steps later than it could (its leaf waits in the ring), which costs some node
 // visits; PT_BVH_RING_MIN trades that against the rounds' occupancy.
-// pair = in-node flag << 31 | (node or leaf-record index) << 6 | ray lane: a node's first leaf has a copy of its record in
-// the node's own line (bytes 80..127: no second request); indices below 2^25 (checked by the host)
+// pair = leaf record index << 6 | ray lane; record indices are below 2^26 (2 x triangles: checked by the host)
 #ifndef PT_BVH_RING_MIN
 #define PT_BVH_RING_MIN 32u
 #endif
 template <bool DET_BOUNDED>
 PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsigned cnt, unsigned lane, const f3& o, const f3& d,
-                          unsigned n_nodes, int ntri)
+                          unsigned n_recs)
 {
     // every lane, as the owner of a ray, publishes its incumbent; a slot nobody improves reads back unchanged
     const unsigned long long k0 = ((unsigned long long)__float_as_uint(L.tmax) << 32) |
@@ -1487,14 +1486,12 @@ PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsi
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool act = lane < cnt;
     const unsigned e = act ? tl.list[(tl.rd + lane) & (PT_TAIL_LIST - 1u)] : 0u;
-    const unsigned ray = e & 63u, idx = (e >> 6) & 0x1ffffffu;
-    const bool in_node = (e >> 31) != 0u;
+    const unsigned ray = e & 63u, idx = e >> 6;
     const unsigned a = ray << 2;
     const f3 po = mk3(pt_from_lane(a, o.x), pt_from_lane(a, o.y), pt_from_lane(a, o.z));
     const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
-    const bool valid = act & (in_node ? idx < n_nodes : idx < (unsigned)ntri);
-    const float4* qp = !valid ? reinterpret_cast<const float4*>(P.bvh)
-                     : in_node ? reinterpret_cast<const float4*>(P.bvh + idx) + 5 : reinterpret_cast<const float4*>(P.ltris + idx);
+    const bool valid = act & (idx < n_recs);
+    const float4* qp = reinterpret_cast<const float4*>(P.bvh + (valid ? idx : 0u));
     const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
     PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
     r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
@@ -1544,10 +1541,10 @@ PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsi
 // child-order table
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const f3& o, const f3& d, pt_lds_u32* stk, unsigned* ovf,
-                         const pt_lds_u8* nxt, PtTail& tl, unsigned lane, unsigned n_nodes, int ntri, unsigned& c_nodes, unsigned& c_leaves,
+                         const pt_lds_u8* nxt, PtTail& tl, unsigned lane, unsigned n_recs, unsigned& c_nodes, unsigned& c_leaves,
                          unsigned long long& c_steps, unsigned long long& c_tsteps)
 {
-    unsigned ht = 0u, lmask = 0u, lbase = 0u, node = 0u;
+    unsigned ht = 0u, cmask = 0u, cbase = 0u;
     if (TALLY) ++c_steps;
     if (trav) {
         if (TALLY) ++c_nodes;
@@ -1556,28 +1553,29 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
             if (L.sp < PT_BVH_LDS_STACK) { L.gbase = stk[(2 * L.sp) * PT_TRACE_THREADS]; L.gm = stk[(2 * L.sp + 1) * PT_TRACE_THREADS]; }
             else { L.gbase = ovf[2 * (L.sp - PT_BVH_LDS_STACK)]; L.gm = ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1]; }
         }
-        // the group's next child: highest priority first; its slot, its rank among the node children
+        // the group's next child: highest priority first; its slot, its rank among its parent's children
         const unsigned slot = nxt[(L.oct << 8) | (L.gm & 255u)];
         L.gm &= ~(1u << slot);
-        node = L.gbase + (unsigned)__popc((L.gm >> 8) & ((1u << slot) - 1u));
-        unsigned h = 0u, imask = 0u, cbase = 0u;
-        if (node < n_nodes) {
+        const unsigned node = L.gbase + (unsigned)__popc((L.gm >> 8) & ((1u << slot) - 1u));
+        unsigned h = 0u, imask = 0u, lmask = 0u;
+        if (node < n_recs) {
             const uint4* np = reinterpret_cast<const uint4*>(P.bvh + node);
-            const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
-#ifdef PT_EXP_EXTRA_LOAD  // EXPERIMENT (never shipped): one more 16-byte load of the node's own line per visit
-            { const uint4 wx = np[5]; asm volatile("" :: "v"(wx.x), "v"(wx.y), "v"(wx.z), "v"(wx.w)); }
-#endif
-            const unsigned meta = w0.w;
-            const float sx = __uint_as_float((meta & 255u) << 23), sy = __uint_as_float(((meta >> 8) & 255u) << 23),
-                        sz = __uint_as_float(((meta >> 16) & 255u) << 23);
-            imask = meta >> 24;
-            cbase = w1.x; lbase = w1.y; lmask = w1.z & 255u;
+            const uint4 w0 = np[0], w2 = np[1], w3 = np[2], w4 = np[3];
+            // header: org.x | org.y << 16, org.z | ex.x << 16 | ex.y << 24, ex.z | imask << 8 | lmask << 16, base
+            const float sx = __uint_as_float(((w0.y >> 16) & 255u) << 23), sy = __uint_as_float((w0.y >> 24) << 23),
+                        sz = __uint_as_float((w0.z & 255u) << 23);
+            imask = (w0.z >> 8) & 255u;
+            lmask = (w0.z >> 16) & 255u;
+            cbase = w0.w;
+            // the origin off its 16-bit grid position: the builder checked the boxes against this very expression
+            const float ox = pt_fma((float)(w0.x & 0xffffu), P.grid.gstep[0], P.grid.gmin[0]);
+            const float oy = pt_fma((float)(w0.x >> 16), P.grid.gstep[1], P.grid.gmin[1]);
+            const float oz = pt_fma((float)(w0.y & 0xffffu), P.grid.gstep[2], P.grid.gmin[2]);
             // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
             // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
             // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
             const float kx = sx * L.ix, ky = sy * L.iy, kz = sz * L.iz;
-            const float cx = (__uint_as_float(w0.x) - o.x) * L.ix, cy = (__uint_as_float(w0.y) - o.y) * L.iy,
-                        cz = (__uint_as_float(w0.z) - o.z) * L.iz;
+            const float cx = (ox - o.x) * L.ix, cy = (oy - o.y) * L.iy, cz = (oz - o.z) * L.iz;
             // near / far planes of all eight children by the direction's signs: qlo x y z = w2.xy w2.zw w3.xy,
             // qhi x y z = w3.zw w4.xy w4.zw (slots 0-3 in the first word, 4-7 in the second)
             const bool px = (L.oct & 1u) != 0u, py = (L.oct & 2u) != 0u, pz = (L.oct & 4u) != 0u;
@@ -1598,6 +1596,7 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
         }
         const unsigned hn = h & imask;
         ht = h & lmask;
+        cmask = imask | lmask;
         // the rest of the old group goes on the stack, the children just hit become the current group
         if ((L.gm & 255u) != 0u && hn != 0u) {
             if (L.sp < PT_BVH_LDS_STACK) { stk[(2 * L.sp) * PT_TRACE_THREADS] = L.gbase; stk[(2 * L.sp + 1) * PT_TRACE_THREADS] = L.gm; }
@@ -1607,7 +1606,7 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
         }
         if (hn != 0u) {
             L.gbase = cbase;
-            L.gm = hn | (imask << 8);
+            L.gm = hn | (cmask << 8);
         }
         --L.budget;
         // a lane with nothing left to enter is done with the nodes (its last leaves may still be in the ring)
@@ -1620,19 +1619,18 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
             if (TALLY) ++c_leaves;
             const unsigned slot = (unsigned)__builtin_ctz(ht);
             ht &= ht - 1u;
-            const unsigned rank = (unsigned)__popc(lmask & ((1u << slot) - 1u));
-            const unsigned pair = rank == 0u ? (0x80000000u | (node << 6) | lane) : (((lbase + rank) << 6) | lane);
-            tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = pair;
+            const unsigned rec = cbase + (unsigned)__popc(cmask & ((1u << slot) - 1u));
+            tl.list[(tl.wr + pt_mbcnt(has)) & (PT_TAIL_LIST - 1u)] = (rec << 6) | lane;
         }
         tl.wr += (unsigned)__popcll(has);
         if (tl.wr - tl.rd >= 64u) {  // (room for the next 64)
             if (TALLY) ++c_tsteps;
-            pt_bvh_round<DET_BOUNDED>(P, L, tl, 64u, lane, o, d, n_nodes, ntri);
+            pt_bvh_round<DET_BOUNDED>(P, L, tl, 64u, lane, o, d, n_recs);
         }
     }
     if (tl.wr - tl.rd >= (unsigned)PT_BVH_RING_MIN) {
         if (TALLY) ++c_tsteps;
-        pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, o, d, n_nodes, ntri);
+        pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, o, d, n_recs);
     }
 }
 
@@ -1641,7 +1639,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
     const int ntri = P.ntri;
-    const unsigned n_nodes = (unsigned)P.bvh_leaves - 1u;
+    const unsigned n_recs = (unsigned)P.bvh_records;
     // LDS: the table of the triangles outside the hierarchy (pass 2 fetches its records per lane: pt_fetch_rec), the
     // stacks of the workgroup's 256 lanes, then every wave's pass-2 tail (ptk_trace_bvh_lds_bytes)
     {
@@ -1698,7 +1696,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             // the pending pairs first: a lane that has no nodes left has its closest hit only once its leaves are tested
             if (tl.wr != tl.rd) {
                 if (TALLY) ++c_tsteps;
-                pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, s.o, s.d, n_nodes, ntri);
+                pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, s.o, s.d, n_recs);
             }
             if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx, n_rays, n_samples);
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
@@ -1725,7 +1723,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             }
             if (__ballot(alive) == 0ull) break;
         }
-        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_nodes, ntri, c_nodes, c_leaves, c_steps, c_tsteps);
+        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_recs, c_nodes, c_leaves, c_steps, c_tsteps);
     }
 
     if (TALLY && P.stats) {

@@ -98,8 +98,8 @@ struct pt_device_s {
     int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
                                 // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
-    PtBvh8Node* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh), sized with prep
-    PtLeafTri* ltris;           // its leaves: the triangles in Morton order
+    PtBvh8Node* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh): its 64-byte records, sized with prep
+    PtBvhGrid bvh_grid;         // the grid of its nodes' origins
     PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
     int* bigidx;
     int nbig;
@@ -223,7 +223,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
-        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid)) != hipSuccess ||  // indices, count, the LBVH's grid
         hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
         hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
@@ -250,7 +250,6 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->prep) hipFree(d->prep);
     if (d->p1tab) hipFree(d->p1tab);
     if (d->bvh) hipFree(d->bvh);
-    if (d->ltris) hipFree(d->ltris);
     if (d->rad) hipFree(d->rad);
     if (d->pmask) hipFree(d->pmask);
     if (d->counters) hipFree(d->counters);
@@ -700,8 +699,6 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         if (d->prep) hipFree(d->prep);
         if (d->p1tab) hipFree(d->p1tab);
         if (d->bvh) hipFree(d->bvh);
-        if (d->ltris) hipFree(d->ltris);
-        d->ltris = nullptr;
         d->prep = nullptr;
         d->p1tab = nullptr;
         d->bvh = nullptr;
@@ -759,22 +756,26 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 {
     if (d->bvh_valid) return PT_OK;
     if (!d->bvh) {
-        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_node_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
-        if (e == hipSuccess) e = hipMalloc(&d->ltris, d->prep_capacity * sizeof(PtLeafTri));
+        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_record_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e)); }
     }
     const size_t temp_bytes = ptk_bvh_temp_bytes(ntri);
     void* temp = nullptr;
     hipError_t e = hipMalloc(&temp, temp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH build workspace allocation failed: %s", hipGetErrorString(e)); }
-    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->ltris, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, temp, temp_bytes,
+    PtBvhGrid* grid_dev = reinterpret_cast<PtBvhGrid*>(d->bigidx + PT_BVH_BIG_MAX + 1);
+    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, grid_dev, temp, temp_bytes,
                       d->stream);
-    int nbig = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&nbig, d->bigidx + PT_BVH_BIG_MAX, sizeof nbig, hipMemcpyDeviceToHost, d->stream);
+    struct { int nbig; PtBvhGrid grid; } back;
+    memset(&back, 0, sizeof back);
+    static_assert(sizeof back == sizeof(int) + sizeof(PtBvhGrid), "count and grid are read back together");
+    if (e == hipSuccess) e = hipMemcpyAsync(&back, d->bigidx + PT_BVH_BIG_MAX, sizeof back, hipMemcpyDeviceToHost, d->stream);
+    int& nbig = back.nbig;
     hipError_t e2 = hipStreamSynchronize(d->stream);  // once per scene upload; the workspace is freed right after
     hipFree(temp);
     if (e != hipSuccess || e2 != hipSuccess) return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     d->nbig = nbig < 0 ? 0 : (nbig > PT_BVH_BIG_MAX ? PT_BVH_BIG_MAX : nbig);
+    d->bvh_grid = back.grid;
     d->bvh_valid = true;
     return PT_OK;
 }
@@ -823,7 +824,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
     if (!use_bvh && rp.num_triangles >= (1 << 26))
         return fail(PT_ERR_INVALID, "the brute-force search packs a triangle index in 26 bits: use PT_OPT_ACCEL 0 or 2 for %d triangles", rp.num_triangles);
     if (use_bvh && rp.num_triangles >= (1 << 25))
-        return fail(PT_ERR_INVALID, "the LBVH search packs a node / leaf index in 25 bits: %d triangles are too many", rp.num_triangles);
+        return fail(PT_ERR_INVALID, "the LBVH search packs a record index (2 x triangles) in 26 bits: %d triangles are too many", rp.num_triangles);
 
     // frames per chunk: radiance staging is 12 B x pixels x frames
     // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
@@ -916,8 +917,8 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = d->prep_p1_lo;
         tp.p1_hi = d->prep_p1_hi;
         tp.bvh = d->bvh;
-        tp.ltris = d->ltris;
-        tp.bvh_leaves = ptk_bvh_leaf_count(rp.num_triangles);
+        tp.bvh_records = (int32_t)ptk_bvh_record_count(rp.num_triangles);
+        tp.grid = d->bvh_grid;
         tp.bigtab = d->bigtab;
         tp.bigidx = d->bigidx;
         tp.nbig = use_bvh ? d->nbig : 0;
