@@ -112,9 +112,7 @@ enum pt_option {
     /* Device::toggleProfiling(PROFILE_RETURN_TIME) (Adl.h:171): launches synchronise and
      * return their duration in ms (AdlKernelUtilsCL.cpp:470-487). */
     PT_OPT_PROFILE_RETURN_TIME = 2,
-    /* which trace kernel renders: 0 = library default, 1 = lane-regenerating waves (the only one
-     * shipped; an octant-sorted experiment of round 1 was measured slower and removed). */
-    PT_OPT_TRACE_VARIANT = 3,
+    /* (3 is not assigned: it selected between trace-kernel variants until only one was left) */
     /* conservative pass-1 filter of the closest-hit search, for A/B timing and parity tests:
      * 0 = the strongest the uploaded scene allows, 1..3 = independent triangles (pt_tri_pass1),
      * 4 = the packed shared-u filter when the scene is made of (a,b,c),(c,d,a) quads (two quads per
@@ -258,6 +256,7 @@ enum {
      * the waves executed for them (a node phase enters one node per participating lane, a triangle phase tests one
      * triangle per participating lane) */
     PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_STEPS = 4 /* node phases */, PT_STAT_BVH_TRI_STEPS = 5,
+    PT_STAT_BVH_MAX_STACK = 6 /* the deepest traversal stack any ray needed (a maximum, not a sum; capacity: 64) */,
     PT_STAT_WORDS = 8
 };
 

@@ -138,6 +138,13 @@ __global__ void pt_bvh_big_finish_kernel(unsigned* __restrict__ bounds, int* __r
     *nbig_out = (int)n;
 }
 
+// the caller's records of the triangles kept out of the hierarchy, in table order (for ptk_prep_triangles: is the table made of quads?)
+__global__ void pt_bvh_big_raw_kernel(const PtRawTriangle* __restrict__ raw, const int* __restrict__ bigidx, int nbig, PtRawTriangle* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nbig) out[k] = raw[bigidx[k]];
+}
+
 __device__ __forceinline__ unsigned pt_expand10(unsigned v)
 {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -515,6 +522,13 @@ __global__ void pt_bvh8_topdown_init_kernel(PtWork8* q, unsigned* counts, unsign
 __global__ void pt_bvh8_zero_kernel(unsigned* p) { *p = 0u; }
 
 }  // namespace
+
+hipError_t ptk_bvh_big_raw(const PtRawTriangle* raw, const int* bigidx, int nbig, PtRawTriangle* out, hipStream_t s)
+{
+    if (nbig <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_bvh_big_raw_kernel, dim3(1), dim3(PT_BVH_BIG_MAX), 0, s, raw, bigidx, nbig, out);
+    return hipGetLastError();
+}
 
 size_t ptk_bvh_temp_bytes(int ntri)
 {

@@ -142,9 +142,12 @@ hipError_t ptk_primary_masks(const PtTraceParams& p, hipStream_t s);
 // det_bounded: every triangle satisfies |e1|_1*|e2|_1 <= PT_DET_BOUND_MAX (short exact reciprocal valid)
 // quads: 0 = independent triangles (pt_tri_pass1); 3 = ntri is even, every pair (2k, 2k+1) is a quad
 //        (a,b,c),(c,d,a), the margins and the packed table p.p1tab are prepared (pt_quad3_pass1)
-// bvh: traverse p.bvh instead of the brute-force two-pass search
+// bvh: traverse p.bvh instead of the brute-force two-pass search; then `quads` is about the table of the big triangles kept out
+//      of the hierarchy (p.bigtab: 3 = made of quads, p.p1tab / p1_lo / p1_hi / quad_delta1 / ray_radius prepared for IT)
 // tally: (bvh only) the measurement variant that adds the search's work counters to p.stats[2..5]
 hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, int quads, bool bvh, bool tally, hipStream_t s);
+// out[k] = raw[bigidx[k]], k < nbig <= PT_BVH_BIG_MAX
+hipError_t ptk_bvh_big_raw(const PtRawTriangle* raw, const int* bigidx, int nbig, PtRawTriangle* out, hipStream_t s);
 static inline size_t ptk_bvh_record_count(int ntri) { return 2 * (size_t)(ntri > 0 ? ntri : 0); }  // < ntri nodes + ntri leaves
 size_t ptk_bvh_temp_bytes(int ntri);
 // prep: the prepared records of the same triangles.  bigtab[PT_BVH_BIG_MAX] / bigidx[PT_BVH_BIG_MAX] / *nbig_dev (device memory)

@@ -844,54 +844,11 @@ PTK_DEV unsigned pt_intersect_primary(pt_const_f32p T, const PtPrepTriangle* tri
     return steps;
 }
 
-// ---- closest hit through the LBVH (pt_bvh.hip) -----------------------------------------------------
-// Stackless traversal along the nodes' miss links; every lane walks its own ray.  At a leaf the
-// reference's exact test runs with pt_tri_pass2's arithmetic; because leaves are met in tree order,
-// not index order, the reference's "first triangle wins an exact tie" (:125 with ascending i)
-// becomes: accept when t < tmax, or t == tmax and the index is lower than the holder's.
-
-template <bool DET_BOUNDED>
-PTK_DEV void pt_tri_exact_unordered(const PtTriRec& r, int i, const f3& o, const f3& d, float& tmax, float& hu, float& hv, int& hidx)
-{
-    float pvx = pt_fma(d.y, r.e2z, -(d.z * r.e2y));
-    float pvy = pt_fma(d.z, r.e2x, -(d.x * r.e2z));
-    float pvz = pt_fma(d.x, r.e2y, -(d.y * r.e2x));
-    float det = pt_fma(r.e1z, pvz, pt_fma(r.e1y, pvy, r.e1x * pvx));
-    float inv_det = DET_BOUNDED ? pt_rcp(det) : 1.0f / det;  // pt_rcp: exact, range-checked (det may be anything here)
-    float tvx = o.x - r.p1x, tvy = o.y - r.p1y, tvz = o.z - r.p1z;
-    float u = pt_fma(tvz, pvz, pt_fma(tvy, pvy, tvx * pvx)) * inv_det;
-    bool ok = !(det < 1e-8f) & !(-det > 1e-8f) & !(u < 0.0f) & !(u > 1.0f);  // :100, :109
-    float qvx = pt_fma(tvy, r.e1z, -(tvz * r.e1y));
-    float qvy = pt_fma(tvz, r.e1x, -(tvx * r.e1z));
-    float qvz = pt_fma(tvx, r.e1y, -(tvy * r.e1x));
-    float v = pt_fma(d.z, qvz, pt_fma(d.y, qvy, d.x * qvx)) * inv_det;
-    ok &= !(v < 0.0f) & !(u + v > 1.0f);  // :117
-    float tt = pt_fma(r.e2z, qvz, pt_fma(r.e2y, qvy, r.e2x * qvx)) * inv_det;
-    ok &= (tt > 0.0f) & ((tt < tmax) | ((tt == tmax) & (i < hidx)));  // :125 in any visiting order
-    tmax = ok ? tt : tmax;
-    hu = ok ? u : hu;
-    hv = ok ? v : hv;
-    hidx = ok ? i : hidx;
-}
-
-// slab test of one box; NaNs (a zero direction component against a coincident plane) are dropped by
-// v_min/v_max, so that axis constrains nothing.  Returns the entry distance in tn.
-PTK_DEV bool pt_slab(const float4& bmin, const float4& bmax, const f3& o, float ix, float iy, float iz, float tmax, float& tn)
-{
-    const float t1x = (bmin.x - o.x) * ix, t2x = (bmax.x - o.x) * ix;
-    const float t1y = (bmin.y - o.y) * iy, t2y = (bmax.y - o.y) * iy;
-    const float t1z = (bmin.z - o.z) * iz, t2z = (bmax.z - o.z) * iz;
-    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-    // a NaN ray fails these: nothing could be accepted for it anyway (every t is NaN)
-    return (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);
-}
-
 // ------------------------------------------------------------------------------------------
 // trace kernels
 // ------------------------------------------------------------------------------------------
 
-// one path: 16 dwords (the unit the octant-sorted kernel moves between lanes)
+// one path: 16 dwords (what a lane holds, and what the per-wave pool parks: pt_pool_push / pt_pool_pop)
 struct PtPath {
     f3 o, d;        // current ray (:257)
     f3 mask, L;     // throughput and radiance (:225-226)
@@ -1023,12 +980,13 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
         // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
         float* out = PT_ARG(rad) + ((size_t)s.fl * PT_ARG(npix_local) + s.lp) * 3u;
-        typedef float pt_f3v __attribute__((ext_vector_type(3)));
+        // (records are 12 bytes apart: the vector type is declared with the 4-byte alignment the address really has)
+        typedef float pt_f3v __attribute__((ext_vector_type(3), aligned(4)));
         pt_f3v v;
         v.x = pt_max(s.L.x, 0.0f);
         v.y = pt_max(s.L.y, 0.0f);
         v.z = pt_max(s.L.z, 0.0f);
-        *reinterpret_cast<pt_f3v*>(out) = v;  // one 12-byte store
+        *reinterpret_cast<pt_f3v*>(out) = v;  // one 12-byte store (global_store_dwordx3)
         n_samples++;
         alive = false;
     }
@@ -1379,9 +1337,7 @@ void pt_trace_tiled_kernel(const PtTraceParams P)
 #ifndef PT_BVH_REFILL
 #define PT_BVH_REFILL 40
 #endif
-#ifndef PT_BVH_TRI_LANES
-#define PT_BVH_TRI_LANES 8
-#endif
+
 
 // dead lanes take the next samples of the wave's range, one by one (no coherence to keep here: the search dominates)
 template <bool LATE>
@@ -1427,18 +1383,41 @@ struct PtBvhLane {
     unsigned gbase, gm;
     unsigned oct;  // bit a set: the ray runs towards +a (children on the low side come first)
     int sp;
-    float ix, iy, iz;
+    float ix, iy, iz;  // 1 / (dir * tmax): distances along the ray in units of tmax (pt_bvh_scale)
     unsigned budget;
 };
+
+// Distances in units of tmax.  The slab test wants, per child, max(entry, 0) <= min(exit, tmax).  With every distance
+// divided by tmax the search interval is [0, 1] -- exactly what the VOP3 `clamp` output modifier clamps to, for free: the 48
+// FMAs of a node step deliver their planes' distances already clamped, the test is one max3, one min3 and ONE comparison,
+// and the 16 v_max / v_min against 0 and tmax of the plain form (9 % of a node step's issue cycles) are gone.  The comparison
+// becomes STRICT: a box wholly beyond tmax has entry = exit = 1 after the clamp (one behind the origin 0 = 0) and must
+// fail; a box that holds a hit point of the ray is entered strictly before it is left (its faces lie PT_BVH_EPS x the scene
+// outside the triangle: pt_bvh.hip), so nothing a triangle needs is lost.  The scaled inverse direction is refreshed whenever
+// tmax shrinks (pt_bvh_round); rounding differences against the unscaled form are ~1e-7 relative, three orders of magnitude
+// inside the boxes' margin.
+PTK_DEV void pt_bvh_scale(PtBvhLane& L, const f3& d)
+{
+    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the boxes' margin), clamped
+    // to +-2^60: a zero component keeps its sign and every product stays finite
+    // tmax in (0, 1e20]; the cap keeps every product finite for a hit at a denormal distance (the interval then ends below 1:
+    // still a superset of [0, tmax])
+    const float it = __builtin_fminf(__builtin_amdgcn_rcpf(L.tmax), 0x1p40f);
+    L.ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -0x1p60f, 0x1p60f) * it;
+    L.iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -0x1p60f, 0x1p60f) * it;
+    L.iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -0x1p60f, 0x1p60f) * it;
+}
+PTK_DEV float pt_fma_clamp(float a, float b, float c)  // min(max(fma(a, b, c), 0), 1): the clamp is an output modifier, no instruction
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // the search of a new ray starts at the root (tmax, hu, hv, hidx are the caller's: the big triangles were searched first)
 PTK_DEV void pt_bvh_lane_start(PtBvhLane& L, const f3& d, int ntri)
 {
-    // 1/dir for the slab tests only (conservative boxes: the error of v_rcp_f32 is far inside the boxes' margin), clamped
-    // to +-2^60: a zero component keeps its sign and every product stays finite
-    L.ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -0x1p60f, 0x1p60f);
-    L.iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -0x1p60f, 0x1p60f);
-    L.iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -0x1p60f, 0x1p60f);
+    pt_bvh_scale(L, d);
     L.oct = (L.ix < 0.0f ? 0u : 1u) | (L.iy < 0.0f ? 0u : 2u) | (L.iz < 0.0f ? 0u : 4u);
     L.gbase = 0u;  // the root (node 0) as a group of one: slot 0
     L.gm = 1u | (1u << 8);
@@ -1532,6 +1511,7 @@ PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsi
         L.hidx = (int)(((unsigned)slot >> 6) & 0x3ffffffu);
         L.hu = pu;
         L.hv = pv;
+        pt_bvh_scale(L, d);
     }
     tl.rd += cnt;
 }
@@ -1542,7 +1522,7 @@ PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsi
 template <bool DET_BOUNDED, bool TALLY>
 PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const f3& o, const f3& d, pt_lds_u32* stk, unsigned* ovf,
                          const pt_lds_u8* nxt, PtTail& tl, unsigned lane, unsigned n_recs, unsigned& c_nodes, unsigned& c_leaves,
-                         unsigned long long& c_steps, unsigned long long& c_tsteps)
+                         unsigned long long& c_steps, unsigned long long& c_tsteps, unsigned& c_maxsp)
 {
     unsigned ht = 0u, cmask = 0u, cbase = 0u;
     if (TALLY) ++c_steps;
@@ -1571,8 +1551,8 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
             const float ox = pt_fma((float)(w0.x & 0xffffu), P.grid.gstep[0], P.grid.gmin[0]);
             const float oy = pt_fma((float)(w0.x >> 16), P.grid.gstep[1], P.grid.gmin[1]);
             const float oz = pt_fma((float)(w0.y & 0xffffu), P.grid.gstep[2], P.grid.gmin[2]);
-            // entry / exit distances straight from the bytes: t = fma(q, step / d, (origin - o) / d) (the products
-            // step * (1/d) are exact: step is a power of two); against decoding the box first this differs by a few
+            // entry / exit distances straight from the bytes, in units of tmax and clamped to [0, 1] (pt_bvh_scale):
+            // t = fma(q, step / (d tmax), (origin - o) / (d tmax)); against decoding the box first this differs by a few
             // ulp of |coordinate| / |d|, orders of magnitude inside the boxes' PT_BVH_EPS margin
             const float kx = sx * L.ix, ky = sy * L.iy, kz = sz * L.iz;
             const float cx = (ox - o.x) * L.ix, cy = (oy - o.y) * L.iy, cz = (oz - o.z) * L.iz;
@@ -1585,12 +1565,12 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
 #define PT_B8(lo_, hi_, k) (float)((((k) < 4 ? (lo_) : (hi_)) >> (8 * ((k) & 3))) & 255u)
 #pragma unroll
             for (int k = 7; k >= 0; --k) {  // (MSB first: slot k ends up in bit k)
-                const float tnx = pt_fma(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma(PT_B8(fx0, fx1, k), kx, cx);
-                const float tny = pt_fma(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma(PT_B8(fy0, fy1, k), ky, cy);
-                const float tnz = pt_fma(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma(PT_B8(fz0, fz1, k), kz, cz);
-                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, L.tmax));
-                h = pt_push_flag(h, PT_LANES(tn <= tf));
+                const float tnx = pt_fma_clamp(PT_B8(nx0, nx1, k), kx, cx), tfx = pt_fma_clamp(PT_B8(fx0, fx1, k), kx, cx);
+                const float tny = pt_fma_clamp(PT_B8(ny0, ny1, k), ky, cy), tfy = pt_fma_clamp(PT_B8(fy0, fy1, k), ky, cy);
+                const float tnz = pt_fma_clamp(PT_B8(nz0, nz1, k), kz, cz), tfz = pt_fma_clamp(PT_B8(fz0, fz1, k), kz, cz);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);  // already within [0, 1] = [0, tmax]
+                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+                h = pt_push_flag(h, PT_LANES(tn < tf));
             }
 #undef PT_B8
         }
@@ -1603,6 +1583,7 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
             else if (L.sp < (int)P.bvh_stack_limit) { ovf[2 * (L.sp - PT_BVH_LDS_STACK)] = L.gbase; ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1] = L.gm; }
             if (L.sp < (int)P.bvh_stack_limit) ++L.sp;
             else atomicOr(P.bvh_flags, PT_BVH_FLAG_STACK);  // the group is lost: the host reports the render as failed
+            if (TALLY) c_maxsp = (unsigned)L.sp > c_maxsp ? (unsigned)L.sp : c_maxsp;
         }
         if (hn != 0u) {
             L.gbase = cbase;
@@ -1634,7 +1615,9 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
     }
 }
 
-template <bool DET_BOUNDED, bool TALLY>
+// BIGQ: the filter of the brute-force search over the big triangles: 0 = independent triangles, 3 = the packed shared-u filter
+// (their table is made of quads -- the Cornell box's walls among a soup -- and the host prepared its pass-1 table)
+template <bool DET_BOUNDED, bool TALLY, int BIGQ>
 PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 {
     const unsigned lane = pt_lane_id();
@@ -1688,7 +1671,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     PtBvhLane L;  // the search's state
     L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1;
     L.gbase = L.gm = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
-    unsigned c_nodes = 0, c_leaves = 0;
+    unsigned c_nodes = 0, c_leaves = 0, c_maxsp = 0;
     unsigned long long c_steps = 0, c_tsteps = 0;
 
     for (;;) {
@@ -1712,8 +1695,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     // shares the key slots with pt_bvh_round and expects them empty: the ring has just been flushed.)
                     int hp = -1;
                     tl.keys[lane] = ~0ull;
-                    pt_intersect_two_pass<DET_BOUNDED, 1, 0>(bigT, P.bigtab, P.nbig, s.o, s.d, start, L.tmax, L.hu, L.hv, hp, 0.0f, 0.0f,
-                                                                 nullptr, 0.0f, 0.0f, tl, lane);
+                    pt_intersect_two_pass<DET_BOUNDED, 1, (DET_BOUNDED ? BIGQ : 0)>(bigT, P.bigtab, P.nbig, s.o, s.d, start, L.tmax, L.hu, L.hv, hp,
+                                                                                      P.quad_delta1, P.ray_radius, (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi, tl, lane);
                     if (start && hp >= 0) L.hidx = P.bigidx[hp];
                 }
                 if (start) {
@@ -1723,7 +1706,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             }
             if (__ballot(alive) == 0ull) break;
         }
-        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_recs, c_nodes, c_leaves, c_steps, c_tsteps);
+        pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_recs, c_nodes, c_leaves, c_steps, c_tsteps, c_maxsp);
     }
 
     if (TALLY && P.stats) {
@@ -1738,6 +1721,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             atomicAdd(&P.stats[4], c_steps);
             atomicAdd(&P.stats[5], c_tsteps);
         }
+        atomicMax(&P.stats[6], (unsigned long long)c_maxsp);  // deepest stack any ray of the launch needed
     }
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
@@ -1747,11 +1731,11 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
 #else
 #define PT_BVH_WAVES_ATTR
 #endif
-template <bool DET_BOUNDED, bool TALLY>
+template <bool DET_BOUNDED, bool TALLY, int BIGQ>
 __global__ __launch_bounds__(PT_TRACE_THREADS) PT_BVH_WAVES_ATTR
 void pt_trace_bvh_kernel(const PtTraceParams P)
 {
-    pt_trace_bvh_body<DET_BOUNDED, TALLY>(P);
+    pt_trace_bvh_body<DET_BOUNDED, TALLY, BIGQ>(P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1900,12 +1884,15 @@ hipError_t ptk_trace(const PtTraceParams& p, int num_blocks, bool det_bounded, i
 {
     if (bvh) {
         const size_t lds = ptk_trace_bvh_lds_bytes();
+        const bool bq = det_bounded && quads == 3;
         if (tally) {
-            if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, true>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            if (bq) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, true, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, true, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         } else {
-            if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
-            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, false>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            if (bq) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, false, 3>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else if (det_bounded) hipLaunchKernelGGL((pt_trace_bvh_kernel<true, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
+            else hipLaunchKernelGGL((pt_trace_bvh_kernel<false, false, 0>), dim3(num_blocks), dim3(PT_TRACE_THREADS), lds, s, p);
         }
         return hipGetLastError();
     }
@@ -1982,7 +1969,7 @@ size_t ptk_trace_bvh_lds_bytes(void)
 int ptk_trace_bvh_blocks_per_cu(void)
 {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_bvh_kernel<true, false>, PT_TRACE_THREADS, ptk_trace_bvh_lds_bytes());
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pt_trace_bvh_kernel<true, false, 3>, PT_TRACE_THREADS, ptk_trace_bvh_lds_bytes());
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

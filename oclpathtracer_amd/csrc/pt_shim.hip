@@ -86,7 +86,7 @@ struct pt_device_s {
     hipStream_t own_stream, stream;
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_variant, opt_quads, opt_accel, opt_tally, opt_pmask, opt_bvh_stack;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_quads, opt_accel, opt_tally, opt_pmask, opt_bvh_stack;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -98,6 +98,10 @@ struct pt_device_s {
     int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
                                 // finite radius, margins and the packed table prepared
     float prep_delta1, prep_ray_radius;  // quad modes 2, 3 (pt_quad2_pass1)
+    float prep_radius;                   // max |vertex - eye|_inf of the prepared scene (NaN when not finite)
+    int big_quads;                       // the LBVH's table of big triangles: 3 = made of quads, its filter table (big_p1tab) and bounds prepared
+    float* big_p1tab;
+    float big_delta1, big_ray_radius, big_p1_lo, big_p1_hi;
     PtBvh8Node* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh): its 64-byte records, sized with prep
     PtBvhGrid bvh_grid;         // the grid of its nodes' origins
     PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
@@ -214,7 +218,6 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_batch = 1;
     d->opt_chunk = 0;
     d->opt_profile = 0;
-    d->opt_variant = 0;
     d->opt_quads = 0;
     d->opt_accel = 0;
     d->opt_pmask = PT_DEFAULT_PRIMARY_MASKS;
@@ -225,6 +228,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
         hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid)) != hipSuccess ||  // indices, count, the LBVH's grid
         hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
+        hipMalloc(&d->big_p1tab, ptk_p1tab_floats(PT_BVH_BIG_MAX) * sizeof(float) + PT_BVH_BIG_MAX * sizeof(PtRawTriangle)) != hipSuccess ||  // + the big triangles' raw records
         hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
         hipStreamDestroy(d->own_stream);
         delete d;
@@ -255,6 +259,7 @@ extern "C" int pt_device_destroy(pt_device_t d)
     if (d->counters) hipFree(d->counters);
     if (d->bigtab) hipFree(d->bigtab);
     if (d->bigidx) hipFree(d->bigidx);
+    if (d->big_p1tab) hipFree(d->big_p1tab);
     if (d->det_bound_dev) hipFree(d->det_bound_dev);
     for (int k = 0; k < PT_PROF_KINDS; ++k)
         for (auto& pr : d->prof_pairs[k]) {
@@ -349,10 +354,6 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
     case PT_OPT_PROFILE_RETURN_TIME:
         d->opt_profile = value ? 1 : 0;
         return PT_OK;
-    case PT_OPT_TRACE_VARIANT:
-        if (value < 0 || value > 1) return fail(PT_ERR_INVALID, "trace variant must be 0 (auto) or 1 (lane-regenerating waves)");
-        d->opt_variant = value;
-        return PT_OK;
     case PT_OPT_QUAD_FILTER:
         if (value < 0 || value > 4) return fail(PT_ERR_INVALID, "quad filter must be 0 (auto), 1..3 (independent triangles) or 4 (packed shared u)");
         d->opt_quads = value;
@@ -382,7 +383,6 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_BATCH_FRAMES: return d->opt_batch;
     case PT_OPT_CHUNK_FRAMES: return d->opt_chunk;
     case PT_OPT_PROFILE_RETURN_TIME: return d->opt_profile;
-    case PT_OPT_TRACE_VARIANT: return d->opt_variant;
     case PT_OPT_QUAD_FILTER: return d->opt_quads;
     case PT_OPT_ACCEL: return d->opt_accel;
     case PT_OPT_BVH_TALLY: return d->opt_tally;
@@ -722,6 +722,7 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     memcpy(&bound, &words[0], sizeof bound);
     memcpy(&radius, &words[2], sizeof radius);
     d->prep_det_bounded = bound <= PT_DET_BOUND_MAX;  // false for NaN / Inf too
+    d->prep_radius = radius;
     const bool pairs = words[1] == 0u && ntri > 0 && (ntri & 1) == 0;  // every (2k, 2k+1) has e2' == -e2
     d->prep_quads = 0;
     d->prep_delta1 = 0.0f;
@@ -776,6 +777,33 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     if (e != hipSuccess || e2 != hipSuccess) return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     d->nbig = nbig < 0 ? 0 : (nbig > PT_BVH_BIG_MAX ? PT_BVH_BIG_MAX : nbig);
     d->bvh_grid = back.grid;
+    // The big triangles are searched by the brute-force two-pass search before every traversal.  When their table is made
+    // of quads (a,b,c),(c,d,a) -- the Cornell box's walls among a soup of small triangles -- it gets the packed shared-u
+    // filter (pt_quad3_pass1) like a quad scene on the brute-force path: same preparation (ensure_prep), on the table.  The
+    // filter's error bound is about where RAYS start: anywhere on the scene, so the radius is the whole scene's.
+    d->big_quads = 0;
+#ifndef PT_EXP_NO_BIGQ  // (A/B builds: the big triangles' search with the plain filter)
+    if (d->nbig >= 2 && (d->nbig & 1) == 0 && d->prep_det_bounded && d->prep_radius <= 1.0e15f) {
+        PtRawTriangle* rawbig = reinterpret_cast<PtRawTriangle*>(d->big_p1tab + ptk_p1tab_floats(PT_BVH_BIG_MAX));
+        HIP_TRY(ptk_bvh_big_raw((const PtRawTriangle*)tris->dptr, d->bigidx, d->nbig, rawbig, d->stream));
+        HIP_TRY(ptk_prep_triangles(rawbig, d->bigtab, d->nbig, d->det_bound_dev, d->stream));  // (rewrites the same records)
+        unsigned int words[PT_PREP_WORDS] = { 0u, 1u, 0x7fc00000u, 1u };
+        HIP_TRY(hipMemcpyAsync(words, d->det_bound_dev, sizeof words, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        if (words[1] == 0u && words[3] == 0u) {
+            const float ray_radius = d->prep_radius * 1.001f + 0.05f;
+            const float diameter = 2.0f * ray_radius * 1.001f;
+            const float delta1 = 128.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
+            HIP_TRY(ptk_prep_quad_margins(d->bigtab, d->nbig, diameter, delta1, d->big_p1tab, d->stream));
+            const float deltaP = 192.0f * 5.9604645e-8f * diameter * diameter * 1.001f;
+            d->big_quads = 3;
+            d->big_delta1 = delta1;
+            d->big_ray_radius = ray_radius;
+            d->big_p1_lo = -deltaP;
+            d->big_p1_hi = (delta1 + deltaP) * 1.001f;
+        }
+    }
+#endif
     d->bvh_valid = true;
     return PT_OK;
 }
@@ -911,11 +939,11 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.batches_per_frame = bpf;
         tp.total_batches = (uint32_t)total_batches;
         tp.batch = batch;
-        tp.quad_delta1 = d->prep_delta1;
-        tp.ray_radius = d->prep_ray_radius;
-        tp.p1tab = d->p1tab;
-        tp.p1_lo = d->prep_p1_lo;
-        tp.p1_hi = d->prep_p1_hi;
+        tp.quad_delta1 = use_bvh ? d->big_delta1 : d->prep_delta1;
+        tp.ray_radius = use_bvh ? d->big_ray_radius : d->prep_ray_radius;
+        tp.p1tab = use_bvh ? d->big_p1tab : d->p1tab;
+        tp.p1_lo = use_bvh ? d->big_p1_lo : d->prep_p1_lo;
+        tp.p1_hi = use_bvh ? d->big_p1_hi : d->prep_p1_hi;
         tp.bvh = d->bvh;
         tp.bvh_records = (int32_t)ptk_bvh_record_count(rp.num_triangles);
         tp.grid = d->bvh_grid;
@@ -927,7 +955,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.bvh_stack_limit = (int32_t)d->opt_bvh_stack;
         if (c == 0 && use_pmask) HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel; geometry may differ per call)
         // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
-        const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
+        const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? (use_bvh ? d->big_quads : d->prep_quads) : 0;
         // persistent grid: fill the chip, but never more waves than batches
         const int wg_waves = PT_TRACE_THREADS / 64;
         uint64_t waves_needed = total_batches;

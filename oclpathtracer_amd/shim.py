@@ -14,14 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_SHIM_LIB") or os.path.join(_HERE, "libptshim.so")
 
 PT_OK = 0
-PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE = range(1, 8)
+PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE, PT_ERR_TRAVERSAL = range(1, 9)
 PT_INFO_NAME, PT_INFO_BOARD, PT_INFO_VENDOR, PT_INFO_VERSION = range(4)
-(PT_OPT_BATCH_FRAMES, PT_OPT_CHUNK_FRAMES, PT_OPT_PROFILE_RETURN_TIME, PT_OPT_TRACE_VARIANT, PT_OPT_QUAD_FILTER, PT_OPT_ACCEL,
- PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS) = range(8)
+PT_OPT_BATCH_FRAMES, PT_OPT_CHUNK_FRAMES, PT_OPT_PROFILE_RETURN_TIME = 0, 1, 2   # (3 is not assigned)
+PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT_BVH_STACK_LIMIT = 4, 5, 6, 7, 8
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64
 PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 8
-PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS = 2, 3, 4, 5
+PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS, PT_STAT_BVH_MAX_STACK = 2, 3, 4, 5, 6
 PT_PROF_TRACE, PT_PROF_FOLD = 0, 1
 PT_STREAM_LEGACY = 1  # hipStreamLegacy: how a caller names the legacy default stream to pt_device_set_stream
 

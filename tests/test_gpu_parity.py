@@ -19,22 +19,19 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4  # BASELINE.json north_star: "pixels within 1e-4 RMS of the OpenCL reference"
 
 
-VARIANTS = [1]  # PT_OPT_TRACE_VARIANT: lane-regenerating waves (the octant-sorted experiment of round 1 is gone)
 
 
-def _render_gpu(device, tris, mats, W, H, frames, *, depth=16, frame_begin=0, fb_init=None, variant=0, **kw):
+def _render_gpu(device, tris, mats, W, H, frames, *, depth=16, frame_begin=0, fb_init=None, **kw):
     from oclpathtracer_amd import shim
     from oclpathtracer_amd.render import Renderer
 
     r = Renderer(device, tris, mats, W, H, **kw)
-    device.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
     try:
         if fb_init is not None:
             r.fb.write(np.ascontiguousarray(fb_init, np.float32), r.local_pixels)
         r.render(frames, frame_begin=frame_begin, max_bounces=depth)
         return r.read()
     finally:
-        device.setOption(shim.PT_OPT_TRACE_VARIANT, 0)
         r.release()
 
 
@@ -42,14 +39,13 @@ GOLDEN_CASES = ["cornell_64x64_f1_d16", "cornell_64x64_f2_d16", "cornell_64x64_f
                 "cornell_40x24_f5_d16"]
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_fused_render_matches_golden(device, cornell, name, variant):
+def test_fused_render_matches_golden(device, cornell, name):
     with open(os.path.join(GOLDEN, "work_counters.json")) as f:
         meta = json.load(f)[name]
     want = np.load(os.path.join(GOLDEN, name + ".npy"))
     tris, mats = cornell
-    got = _render_gpu(device, tris, mats, meta["W"], meta["H"], meta["frames"], depth=meta["max_bounces"], variant=variant)
+    got = _render_gpu(device, tris, mats, meta["W"], meta["H"], meta["frames"], depth=meta["max_bounces"])
     assert_fb_equal(got, want, name)
     assert rms_diff(got, want) <= RMS_TOL
 
@@ -59,21 +55,18 @@ def test_fused_render_matches_golden(device, cornell, name, variant):
                                               (512, 512, 4, 2),        # configs[1] shape, fewer frames
                                               (96, 33, 7, 16),         # ragged
                                               (1, 1, 3, 16), (64, 1, 2, 16), (1, 70, 2, 5)])
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_fused_render_matches_oracle(device, cornell, oracle, W, H, frames, depth, variant):
+def test_fused_render_matches_oracle(device, cornell, oracle, W, H, frames, depth):
     tris, mats = cornell
     want, st = oracle.render(tris, mats, W, H, frames, max_bounces=depth, want_stats=True)
     from oclpathtracer_amd import shim
     from oclpathtracer_amd.render import Renderer
 
     r = Renderer(device, tris, mats, W, H, want_stats=True)
-    device.setOption(shim.PT_OPT_TRACE_VARIANT, variant)
     try:
         r.render(frames, max_bounces=depth)
         got = r.read()
         gst = r.read_stats()
     finally:
-        device.setOption(shim.PT_OPT_TRACE_VARIANT, 0)
         r.release()
     assert_fb_equal(got, want, "%dx%d f%d d%d" % (W, H, frames, depth))
     assert rms_diff(got, want) <= RMS_TOL
@@ -90,8 +83,7 @@ def test_configs1_direct_full_size(device, cornell, oracle):
     assert_fb_equal(got, want, "C2")
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_configs2_full_size_sampled_pixels(device, cornell, oracle, variant):
+def test_configs2_full_size_sampled_pixels(device, cornell, oracle):
     """BASELINE configs[2]: 1024x1024, 256 spp, depth 16 rendered in full on the GPU; the oracle
     recomputes 2048 seeded pixel positions through all 256 frames (pixels are independent,
     GenerateColors.cl:305-321) and those must match bit for bit.  Whole-image properties: w == 1
@@ -99,7 +91,7 @@ def test_configs2_full_size_sampled_pixels(device, cornell, oracle, variant):
     tris, mats = cornell
     W = H = 1024
     frames = 256
-    got = _render_gpu(device, tris, mats, W, H, frames, variant=variant).reshape(H * W, 4)
+    got = _render_gpu(device, tris, mats, W, H, frames).reshape(H * W, 4)
     assert np.all(got[:, 3] == 1.0)
     assert not np.any(got[:, :3] < 0)
     rng = np.random.default_rng(20261004)
@@ -236,15 +228,14 @@ def test_stripe_sharding_reassembles_bit_exact(device, cornell, n_ranks, stripe_
     assert_fb_equal(out, full, "assembled image")
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_soup_scene_runtime_triangle_count(device, oracle, variant):
+def test_soup_scene_runtime_triangle_count(device, oracle):
     """Runtime N_tri / N_mat (BASELINE configs[4] shape at a size the oracle finishes quickly)."""
     from oclpathtracer_amd import scene
 
     tris, mats = scene.make_soup(2000)
     W, H, frames = 48, 32, 2
     want = oracle.render(tris, mats, W, H, frames)
-    got = _render_gpu(device, tris, mats, W, H, frames, variant=variant)
+    got = _render_gpu(device, tris, mats, W, H, frames)
     assert_fb_equal(got, want, "soup 2000")
 
 
