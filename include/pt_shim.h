@@ -280,6 +280,13 @@ int pt_profile_reset(pt_device_t dev);
 int pt_assemble_stripes(pt_device_t dev, pt_buffer_t gathered, pt_buffer_t image, int width,
                         int height, int stripe_rows, int n_ranks, int slab_rows, pt_event_t ev);
 
+/* The same on a stream of the caller's (a hipStream_t, e.g. torch.cuda.Stream().cuda_stream) instead of the device
+ * handle's: rank 0 of an N-rank render assembles image k behind its collective while render k + 1 already occupies the
+ * handle's stream (the reference is single-device and has no counterpart).  The caller orders the stream
+ * against the producer of `gathered` and the consumers of `image` (events); deferred frames are submitted first. */
+int pt_assemble_stripes_on(pt_device_t dev, pt_buffer_t gathered, pt_buffer_t image, int width, int height,
+                           int stripe_rows, int n_ranks, int slab_rows, void* hip_stream);
+
 /* Output stage on the device: rgb8[i] = f2c(sqrtf(fb[i].xyz))
  * of test/RaytraceTest.cpp:78-83,280-285, written as int32 triplets (what "%d %d %d " prints). */
 int pt_tonemap_ppm(pt_device_t dev, pt_buffer_t framebuffer, pt_buffer_t rgb_i32, size_t num_pixels,

@@ -1023,11 +1023,23 @@ extern "C" int pt_render_frames(pt_device_t d, pt_buffer_t triangles, pt_buffer_
     return render_internal(d, triangles, materials, framebuffer, *params, 0, stats, ev);
 }
 
-extern "C" int pt_assemble_stripes(pt_device_t d, pt_buffer_t gathered, pt_buffer_t image, int width, int height,
-                                   int stripe_rows, int n_ranks, int slab_rows, pt_event_t ev)
+static int assemble_check(pt_device_s* d, pt_buffer_s* gathered, pt_buffer_s* image, int width, int height, int stripe_rows, int n_ranks, int slab_rows);
+
+extern "C" int pt_assemble_stripes_on(pt_device_t d, pt_buffer_t gathered, pt_buffer_t image, int width, int height,
+                                      int stripe_rows, int n_ranks, int slab_rows, void* hip_stream)
 {
     int rc = use_device(d);
     if (rc) return rc;
+    if (!hip_stream) return fail(PT_ERR_INVALID, "hip_stream == NULL (pt_assemble_stripes uses the handle's own stream)");
+    if ((rc = assemble_check(d, gathered, image, width, height, stripe_rows, n_ranks, slab_rows)) || (rc = flush_pending(d))) return rc;
+    HIP_TRY(ptk_assemble_stripes((const float4*)gathered->dptr, (float4*)image->dptr, width, height, stripe_rows, n_ranks,
+                                 slab_rows, (hipStream_t)hip_stream));
+    image->version++;
+    return PT_OK;
+}
+
+static int assemble_check(pt_device_s* d, pt_buffer_s* gathered, pt_buffer_s* image, int width, int height, int stripe_rows, int n_ranks, int slab_rows)
+{
     if (!gathered || !image) return fail(PT_ERR_INVALID, "null buffer handle");
     if (gathered->dev != d || image->dev != d) return fail(PT_ERR_INVALID, "buffer belongs to another device");
     if (width < 1 || height < 1 || stripe_rows < 1 || n_ranks < 1 || slab_rows < 0) return fail(PT_ERR_INVALID, "invalid geometry");
@@ -1035,6 +1047,15 @@ extern "C" int pt_assemble_stripes(pt_device_t d, pt_buffer_t gathered, pt_buffe
         if (pt_local_rows(height, stripe_rows, n_ranks, r) > slab_rows) return fail(PT_ERR_INVALID, "slab_rows too small for rank %d", r);
     if ((size_t)n_ranks * slab_rows * width * sizeof(float4) > gathered->bytes) return fail(PT_ERR_RANGE, "gathered buffer too small");
     if ((size_t)width * height * sizeof(float4) > image->bytes) return fail(PT_ERR_RANGE, "image buffer too small");
+    return PT_OK;
+}
+
+extern "C" int pt_assemble_stripes(pt_device_t d, pt_buffer_t gathered, pt_buffer_t image, int width, int height,
+                                   int stripe_rows, int n_ranks, int slab_rows, pt_event_t ev)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if ((rc = assemble_check(d, gathered, image, width, height, stripe_rows, n_ranks, slab_rows))) return rc;
     if ((rc = flush_pending(d)) || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_assemble_stripes((const float4*)gathered->dptr, (float4*)image->dptr, width, height, stripe_rows, n_ranks,
                                  slab_rows, d->stream));

@@ -118,7 +118,11 @@ class StripeImage:
         self._slabs = []
         self._gbufs = []
         self._ibuf = None
+        self._asm_stream = None
         if rank == 0 and world > 1:
+            # the assembly kernel gets a stream of its own: behind the collective, beside the next render (on the shim
+            # stream it would queue behind that render and every image would arrive one render late)
+            self._asm_stream = torch.cuda.Stream(device=self.cuda)
             # gather destinations and the assembled image live for the object's lifetime: a render loop
             # allocates, wraps and synchronises nothing per step
             self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=self.cuda)
@@ -179,13 +183,14 @@ class StripeImage:
             self._collected[slot] = ev             # the slot may be rendered into again after this
         if self.rank != 0:
             return None
-        if self.pipelined:
-            self.stream.wait_event(self._collected[slot])
-        else:
-            self.stream.wait_stream(cur)           # collective -> assembly kernel (reads _slabs)
-        shim.check(shim.load().pt_assemble_stripes(self.dev._h, self._gbufs[slot]._h, self._ibuf._h, self.width, self.height,
-                                                   self.plan.stripe_rows, self.world, self.plan.slab_rows, None))
-        cur.wait_stream(self.stream)           # assembly -> whoever consumes self.image
+        # collective -> assembly kernel (reads _slabs[slot], writes self.image) on its own stream -> whoever consumes
+        # self.image on the current stream.  (The next collective into this slot's slab and the next assembly into
+        # self.image are enqueued on / behind the current stream, which has waited for this assembly: no overlap.)
+        self._asm_stream.wait_stream(cur)
+        shim.check(shim.load().pt_assemble_stripes_on(self.dev._h, self._gbufs[slot]._h, self._ibuf._h, self.width, self.height,
+                                                      self.plan.stripe_rows, self.world, self.plan.slab_rows,
+                                                      self._asm_stream.cuda_stream))
+        cur.wait_stream(self._asm_stream)
         return self.image
 
     def reset_stats(self) -> None:

@@ -101,6 +101,7 @@ SIGNATURES = {
     "pt_profile_query": (_c.c_int, [_H, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
     "pt_profile_reset": (_c.c_int, [_H]),
     "pt_assemble_stripes": (_c.c_int, [_H, _H, _H, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _H]),
+    "pt_assemble_stripes_on": (_c.c_int, [_H, _H, _H, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "pt_tonemap_ppm": (_c.c_int, [_H, _H, _H, _c.c_size_t, _H]),
 }
 

@@ -80,16 +80,17 @@ def test_stripe_image_is_ordered_against_torch_without_host_sync(device, cornell
         img.release()
 
 
-def _run_world(world, backend, tmp_path, ndev_needed, extra=()):
+def _run_world(world, backend, tmp_path, ndev_needed, extra=(), geom=None):
     port = _free_port()
     out = str(tmp_path / "image.npy")
+    w, h, frames, stripe = geom or (W, H, FRAMES, STRIPE)
     procs = []
     for rank in range(world):
         env = dict(os.environ)
         env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), backend, out,
-                                       str(W), str(H), str(FRAMES), str(STRIPE)] + list(extra), env=env,
+                                       str(w), str(h), str(frames), str(stripe)] + list(extra), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -121,6 +122,47 @@ def test_world2_pipelined_gathers(device, cornell, tmp_path):
     two = shim.load().pt_device_count() >= 2
     got = _run_world(2, "nccl" if two else "gloo", tmp_path, 2 if two else 1, extra=("pipelined",))
     assert_fb_equal(got.reshape(-1, 4), want, "world-2 pipelined gathers vs one process")
+
+
+def test_world3_pipelined_with_a_ragged_last_period(device, cornell, tmp_path):
+    """Three ranks, 4-row stripes (bench.py's), a height that leaves the last period of stripes incomplete (200 = 16 x 12 + 8:
+    rank 0 and 1 own one stripe more than rank 2, whose slab is zero-padded in the gather), the pipelined loop, the assembly
+    on its own stream.  gloo through the host when fewer than three devices are visible."""
+    from oclpathtracer_amd import shim
+    from oclpathtracer_amd.render import Renderer
+
+    w, h, frames, stripe = 192, 200, 5, 4
+    tris, mats = cornell
+    r = Renderer(device, tris, mats, w, h)
+    try:
+        r.render(frames)
+        want = r.read()
+    finally:
+        r.release()
+    three = shim.load().pt_device_count() >= 3
+    got = _run_world(3, "nccl" if three else "gloo", tmp_path, 3 if three else 1, extra=("pipelined",), geom=(w, h, frames, stripe))
+    assert_fb_equal(got.reshape(-1, 4), want, "world-3 pipelined, ragged stripes vs one process")
+
+
+def test_configs3_geometry_gather_and_assembly_rehearsal(device, cornell, oracle, tmp_path):
+    """BASELINE configs[3]'s image -- 2048 x 2048, 64 MiB of float4 -- through the whole N-rank path at full size: two rank
+    processes (sharing the one MI355X: gloo through the host; RCCL with two devices) render their 4-row stripes, gather
+    32 MiB slabs and assemble.  Few frames (the arithmetic at full spp is test_configs3_one_rank_of_eight_full_size's
+    business); 24 sampled rows against the oracle, the w lane and the finiteness of the whole image."""
+    from oclpathtracer_amd import shim
+
+    w = h = 2048
+    frames, stripe = 3, 4
+    two = shim.load().pt_device_count() >= 2
+    got = _run_world(2, "nccl" if two else "gloo", tmp_path, 2 if two else 1, extra=("pipelined",), geom=(w, h, frames, stripe))
+    assert got.shape == (h, w, 4)
+    assert np.all(got[..., 3] == 1.0) and np.isfinite(got).all()
+    tris, mats = cornell
+    rows = np.unique(np.concatenate([np.array([0, 3, 4, 7, 8, h - 1, h - 4, h - 5]), np.random.default_rng(3).integers(0, h, 16)]))
+    for row in rows:
+        fb = np.zeros((h * w, 4), np.float32)
+        oracle.render(tris, mats, w, h, frames, fb=fb, gid_begin=int(row) * w, gid_count=w)
+        assert_fb_equal(got[row].reshape(-1, 4), fb[row * w:(row + 1) * w], "2048^2 two-rank image, row %d" % row)
 
 
 def test_world2_nccl(device, cornell, tmp_path):
