@@ -258,8 +258,14 @@ def test_tonemap_matches_host_f2c(device, cornell):
     finally:
         src.release()
         dst.release()
-    want = scene.f2c(fb[:, :3]).reshape(-1)
+    # test/RaytraceTest.cpp:78-83 and :280-285 restated HERE (not the product's scene.f2c): `a *= 255; return min((int)a, 255)`
+    # of sqrtf(v); (int) of a float on the reference's x86 host is cvttss2si: NaN and out-of-range values give INT_MIN
+    with np.errstate(invalid="ignore", over="ignore"):
+        a = np.sqrt(fb[:, :3].astype(np.float32)) * np.float32(255.0)
+    trunc = np.where(np.isfinite(a) & (np.abs(a) < 2147483648.0), np.trunc(np.where(np.isfinite(a), a, 0.0)), -2147483648.0).astype(np.int64)
+    want = np.minimum(trunc, 255).astype(np.int32).reshape(-1)
     assert np.array_equal(out, want)
+    assert np.array_equal(want, scene.f2c(fb[:, :3]).reshape(-1))   # ... and the product's host-side f2c agrees with it
 
 
 def _variant_scene(kind):

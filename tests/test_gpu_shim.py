@@ -344,9 +344,10 @@ def test_device_transcendentals_match_oracle_bitwise(device, oracle):
             assert np.array_equal(g.view(np.uint32)[~gn], w.view(np.uint32)[~wn]), "column %d" % col
 
 
-def test_progressive_driver_matches_one_shot(device, cornell):
+def test_progressive_driver_matches_one_shot(device, cornell, oracle):
     """resumable accumulation + double-buffered asynchronous readback.  Snapshots
-    arrive in order, never block the producer, and every one equals a one-shot render of its frames."""
+    arrive in order, never block the producer, and every one equals a one-shot render of its frames --
+    the GPU's own AND the CPU oracle's (GenerateColors.cl:314-321 makes a pixel a function of its frames alone)."""
     from oclpathtracer_amd.progressive import ProgressiveRenderer
     from oclpathtracer_amd.render import Renderer
 
@@ -375,3 +376,4 @@ def test_progressive_driver_matches_one_shot(device, cornell):
         finally:
             r.release()
         assert_fb_equal(img, want, "progressive snapshot at %d frames" % f)
+        assert_fb_equal(img, oracle.render(tris, mats, W, H, f), "progressive snapshot at %d frames vs the oracle" % f)

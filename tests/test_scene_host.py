@@ -1,11 +1,14 @@
 """Host logic that needs no GPU: scene ingestion, soup generator, PPM output, stripe index math."""
 import os
 import struct
+import sys
 
 import numpy as np
 import pytest
 
 from oclpathtracer_amd import scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_parse_rejects_truncated_and_bad_indices(tmp_path):
@@ -115,3 +118,44 @@ def test_binary_ppm(tmp_path):
     p = tmp_path / "o6.ppm"
     scene.write_ppm_binary(str(p), rgb, 2, 2)
     assert p.read_bytes() == b"P6\n2 2\n255\n" + bytes([0, 127, 255, 255, 255, 255, 51, 76, 102, 0, 255, 7])
+
+
+def test_bench_names_the_baseline_workloads():
+    """bench.py --config k selects BASELINE.json's configs[k] by name; overriding a single value drops the name."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    want = {1: (512, 512, 64, 2, 0), 2: (1024, 1024, 256, 16, 0), 3: (2048, 2048, 1024, 16, 0), 4: (1024, 1024, 256, 16, 1_000_000)}
+    for k, (w, h, spp, depth, soup) in want.items():
+        a = bench.parse_args(["--config", str(k)])
+        assert (a.width, a.height, a.spp, a.depth, a.soup) == (w, h, spp, depth, soup) and a.named
+    a = bench.parse_args([])
+    assert a.config == 2 and a.named and a.gpus == 1 and a.steps >= 1
+    a = bench.parse_args(["--config", "3", "--spp", "8", "--steps", "2"])
+    assert (a.width, a.spp, a.steps) == (2048, 8, 2) and not a.named
+    a = bench.parse_args(["--soup", "5000", "--spp", "4"])
+    assert a.soup == 5000 and not a.named
+
+
+def test_bench_stops_all_ranks_when_one_fails():
+    """spawn_ranks used to wait for rank 0 alone.  Without a GPU every rank exits at once with an error; the parent
+    must come back with a non-zero code in seconds, not sit in a rendezvous."""
+    import subprocess
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: the ranks would run")
+    except ImportError:
+        pass
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "32",
+                        "--height", "32", "--spp", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=170)
+    assert p.returncode != 0
+    assert b"rank(s) failed first" in p.stderr, p.stderr[-800:]
+    assert time.time() - t0 < 150
