@@ -986,11 +986,7 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         v.x = pt_max(s.L.x, 0.0f);
         v.y = pt_max(s.L.y, 0.0f);
         v.z = pt_max(s.L.z, 0.0f);
-#ifdef PT_EXP_NT_RAD
-        __builtin_nontemporal_store(v, reinterpret_cast<pt_f3v*>(out));
-#else
         *reinterpret_cast<pt_f3v*>(out) = v;  // one 12-byte store (global_store_dwordx3)
-#endif
         n_samples++;
         alive = false;
     }
@@ -1475,14 +1471,7 @@ PTK_DEV void pt_bvh_round(const PtTraceParams& P, PtBvhLane& L, PtTail& tl, unsi
     const f3 pd = mk3(pt_from_lane(a, d.x), pt_from_lane(a, d.y), pt_from_lane(a, d.z));
     const bool valid = act & (idx < n_recs);
     const float4* qp = reinterpret_cast<const float4*>(P.bvh + (valid ? idx : 0u));
-#ifdef PT_EXP_NT_LEAVES  // EXPERIMENT: leaf records are read once per hit box and never again soon: keep them from evicting node lines
-    typedef float pt_v4f __attribute__((ext_vector_type(4)));
-    const pt_v4f* qn = reinterpret_cast<const pt_v4f*>(qp);
-    const pt_v4f n0 = __builtin_nontemporal_load(qn), n1 = __builtin_nontemporal_load(qn + 1), n2 = __builtin_nontemporal_load(qn + 2);
-    const float4 q0 = make_float4(n0.x, n0.y, n0.z, n0.w), q1 = make_float4(n1.x, n1.y, n1.z, n1.w), q2 = make_float4(n2.x, n2.y, n2.z, n2.w);
-#else
     const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
-#endif
     PtTriRec r;  // p1.xyz e1.x | e1.yz e2.xy | e2.z index ...
     r.p1x = q0.x; r.p1y = q0.y; r.p1z = q0.z;
     r.e1x = q0.w; r.e1y = q1.x; r.e1z = q1.y;
