@@ -1686,11 +1686,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             const bool start = alive && !trav;
             if (__ballot(start) != 0ull) {
                 if (start) { L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1; }
-#ifdef PT_EXP_NOBIG  // EXPERIMENT (never shipped; wrong pixels): what the brute-force search of the big triangles costs
-                if (false) {
-#else
                 if (P.nbig > 0) {
-#endif
                     // the triangles outside the hierarchy, in ascending index order; hp = position in their table.  (Its tail
                     // shares the key slots with pt_bvh_round and expects them empty: the ring has just been flushed.)
                     int hp = -1;
