@@ -1692,7 +1692,8 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                     int hp = -1;
                     tl.keys[lane] = ~0ull;
                     pt_intersect_two_pass<DET_BOUNDED, 1, (DET_BOUNDED ? BIGQ : 0)>(bigT, P.bigtab, P.nbig, s.o, s.d, start, L.tmax, L.hu, L.hv, hp,
-                                                                                      P.quad_delta1, P.ray_radius, (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi, tl, lane);
+                                                                                      P.quad_delta1, P.ray_radius, (pt_const_f32p)P.p1tab, P.p1_lo, P.p1_hi, tl, lane,
+                                                                                      PT_VALIDATE_FILTER && !TALLY && P.stats ? P.stats + 2 : nullptr);  // (diagnostic build: tools/validate_filter.py)
                     if (start && hp >= 0) L.hidx = P.bigidx[hp];
                 }
                 if (start) {

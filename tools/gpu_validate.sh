@@ -14,6 +14,12 @@ for qf in 0 1; do
     [ ${PIPESTATUS[0]} -ne 0 ] && rc=1
   done
 done
+for qf in 0 1; do
+  for scene in lbvh:2000 lbvh:200000; do   # the big triangles' search inside the LBVH kernel (packed filter / independent triangles)
+    timeout -k 10 300 python tools/validate_filter.py $scene 512 512 $SPP $qf 2>&1 | tee -a gpurun_out/filter_validation.txt
+    [ ${PIPESTATUS[0]} -ne 0 ] && rc=1
+  done
+done
 for geo in "64 64 256" "200 50 256" "33 97 256" "2048 2048 8" "512 512 512"; do
   for scene in cornell scaled skewed tiny random:1001 random:1005; do
     timeout -k 10 300 python tools/validate_filter.py $scene $geo 0 2>&1 | tee -a gpurun_out/filter_validation.txt

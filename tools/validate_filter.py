@@ -19,6 +19,8 @@ if kind == "rolled":          # pairs broken: per-triangle filter
     t = np.roll(t, 1)
 elif kind == "soup":
     t, m = scene.make_soup(200)
+elif kind.startswith("lbvh:"):    # a soup large enough for the LBVH: what is validated is the filter of the brute-force search over
+    t, m = scene.make_soup(int(kind.split(":")[1]))   # the BIG triangles kept out of the hierarchy (the Cornell box's 36: quads -> packed filter)
 elif kind == "scaled":
     t = t.copy()
     for f in ("p1", "p2", "p3"):
