@@ -543,7 +543,7 @@ size_t ptk_bvh_temp_bytes(int ntri)
 
 // work: 36 n bytes of cost tables, two frontiers of 8 n bytes, counts and counters
 static hipError_t pt_bvh8_build_sah(const PtBvhNode* nodes, const int* parent, int nleaves, int* flags, const unsigned long long* sorted,
-                                    const PtPrepTriangle* prep, const PtBvhGrid* grid, PtBvh8Node* recs, char* work, hipStream_t s)
+                                    const PtPrepTriangle* prep, const PtBvhGrid* grid, PtBvh8Node* recs, char* work, unsigned* used_dev, hipStream_t s)
 {
     const size_t n = (size_t)nleaves;
     work = (char*)(((uintptr_t)work + 15) & ~(uintptr_t)15);
@@ -566,11 +566,12 @@ static hipError_t pt_bvh8_build_sah(const PtBvhNode* nodes, const int* parent, i
         hipLaunchKernelGGL(pt_bvh8_topdown_kernel, tgrd, blk, 0, s, nodes, tab, in, counts + (lvl & 1), outq, counts + ((lvl + 1) & 1), counters, sorted,
                            prep, grid, recs);
     }
+    if (used_dev) return hipMemcpyAsync(used_dev, counters, sizeof(unsigned), hipMemcpyDeviceToDevice, s);  // records in use (nodes + leaves)
     return hipGetLastError();
 }
 
 hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* recs,
-                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, void* temp, size_t temp_bytes, hipStream_t s)
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, unsigned* used_dev, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (ntri < 2) return hipErrorInvalidValue;  // callers use the hierarchy for ntri >= 2 only
     const size_t n = (size_t)ntri;
@@ -603,5 +604,5 @@ hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, i
     hipLaunchKernelGGL(pt_bvh_hierarchy_kernel, lgrd, blk, 0, s, sorted, nleaves, nodes, parent, right_child);
     hipLaunchKernelGGL(pt_bvh_refit_kernel, lgrd, blk, 0, s, raw, sorted, nleaves, bounds, nodes, parent, right_child, flags);
     // (the sort is done with its workspace by now: the collapse's tables live at the end of `temp`)
-    return pt_bvh8_build_sah(nodes, parent, nleaves, flags, sorted, prep, grid_dev, recs, (char*)temp + temp_bytes - (36 * n + 16 * n + 256), s);
+    return pt_bvh8_build_sah(nodes, parent, nleaves, flags, sorted, prep, grid_dev, recs, (char*)temp + temp_bytes - (36 * n + 16 * n + 256), used_dev, s);
 }

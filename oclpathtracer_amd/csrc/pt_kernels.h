@@ -154,8 +154,10 @@ size_t ptk_bvh_temp_bytes(int ntri);
 // receive the triangles kept OUT of the hierarchy (pt_bvh.hip: PT_BVH_BIG_DIV): their prepared records and indices, ascending
 #define PT_BVH_BIG_MAX 64
 // recs[ptk_bvh_record_count(ntri)] (device memory) receives the hierarchy the trace kernel walks, *grid_dev its origin grid
+// *used_dev (device memory, may be null) receives the number of records in use
 hipError_t ptk_bvh_build(const PtRawTriangle* raw, const PtPrepTriangle* prep, int ntri, PtBvh8Node* recs,
-                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, void* temp, size_t temp_bytes, hipStream_t s);
+                         PtPrepTriangle* bigtab, int* bigidx, int* nbig_dev, PtBvhGrid* grid_dev, unsigned* used_dev, void* temp, size_t temp_bytes,
+                         hipStream_t s);
 #define PT_DET_BOUND_MAX 2.0e19f
 #define PT_BVH_AUTO_MIN 512      // PT_OPT_ACCEL = 0 uses the BVH from this many triangles on
 hipError_t ptk_fold(const PtFoldParams& p, hipStream_t s);

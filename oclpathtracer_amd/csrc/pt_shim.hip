@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -104,6 +105,7 @@ struct pt_device_s {
     float big_delta1, big_ray_radius, big_p1_lo, big_p1_hi;
     PtBvh8Node* bvh;             // LBVH of the prepared scene (built on demand: ensure_bvh): its 64-byte records, sized with prep
     PtBvhGrid bvh_grid;         // the grid of its nodes' origins
+    size_t bvh_records;         // records in use (nodes + leaves)
     PtPrepTriangle* bigtab;     // the triangles kept out of the hierarchy (PT_BVH_BIG_MAX records + indices + count)
     int* bigidx;
     int nbig;
@@ -226,7 +228,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
-        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid)) != hipSuccess ||  // indices, count, the LBVH's grid
+        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid) + sizeof(unsigned)) != hipSuccess ||  // indices, count, the LBVH's grid, records in use
         hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
         hipMalloc(&d->big_p1tab, ptk_p1tab_floats(PT_BVH_BIG_MAX) * sizeof(float) + PT_BVH_BIG_MAX * sizeof(PtRawTriangle)) != hipSuccess ||  // + the big triangles' raw records
         hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
@@ -765,11 +767,11 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     hipError_t e = hipMalloc(&temp, temp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH build workspace allocation failed: %s", hipGetErrorString(e)); }
     PtBvhGrid* grid_dev = reinterpret_cast<PtBvhGrid*>(d->bigidx + PT_BVH_BIG_MAX + 1);
-    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, grid_dev, temp, temp_bytes,
-                      d->stream);
-    struct { int nbig; PtBvhGrid grid; } back;
+    e = ptk_bvh_build((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->bvh, d->bigtab, d->bigidx, d->bigidx + PT_BVH_BIG_MAX, grid_dev,
+                      reinterpret_cast<unsigned*>(grid_dev + 1), temp, temp_bytes, d->stream);
+    struct { int nbig; PtBvhGrid grid; unsigned used; } back;
     memset(&back, 0, sizeof back);
-    static_assert(sizeof back == sizeof(int) + sizeof(PtBvhGrid), "count and grid are read back together");
+    static_assert(sizeof back == sizeof(int) + sizeof(PtBvhGrid) + sizeof(unsigned), "count, grid and records in use are read back together");
     if (e == hipSuccess) e = hipMemcpyAsync(&back, d->bigidx + PT_BVH_BIG_MAX, sizeof back, hipMemcpyDeviceToHost, d->stream);
     int& nbig = back.nbig;
     hipError_t e2 = hipStreamSynchronize(d->stream);  // once per scene upload; the workspace is freed right after
@@ -777,6 +779,11 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     if (e != hipSuccess || e2 != hipSuccess) return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     d->nbig = nbig < 0 ? 0 : (nbig > PT_BVH_BIG_MAX ? PT_BVH_BIG_MAX : nbig);
     d->bvh_grid = back.grid;
+    d->bvh_records = std::min<size_t>(back.used, ptk_bvh_record_count(ntri));   // (indices are checked against this: a tighter bound than the capacity)
+    if (getenv("PT_SHIM_DEBUG"))
+        fprintf(stderr, "pt_shim: LBVH over %d triangles: %u records in use (%u nodes, %.2f children per node), %d big triangles outside\n", ntri, back.used,
+                back.used > (unsigned)ntri ? back.used - (unsigned)(ntri - d->nbig) : 0u,
+                back.used > (unsigned)ntri ? (double)(back.used - 1) / (double)(back.used - (unsigned)(ntri - d->nbig)) : 0.0, d->nbig);
     // The big triangles are searched by the brute-force two-pass search before every traversal.  When their table is made
     // of quads (a,b,c),(c,d,a) -- the Cornell box's walls among a soup of small triangles -- it gets the packed shared-u
     // filter (pt_quad3_pass1) like a quad scene on the brute-force path: same preparation (ensure_prep), on the table.  The
@@ -945,7 +952,7 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         tp.p1_lo = use_bvh ? d->big_p1_lo : d->prep_p1_lo;
         tp.p1_hi = use_bvh ? d->big_p1_hi : d->prep_p1_hi;
         tp.bvh = d->bvh;
-        tp.bvh_records = (int32_t)ptk_bvh_record_count(rp.num_triangles);
+        tp.bvh_records = (int32_t)d->bvh_records;
         tp.grid = d->bvh_grid;
         tp.bigtab = d->bigtab;
         tp.bigidx = d->bigidx;
