@@ -197,7 +197,7 @@ int pt_event_elapsed_ns(pt_event_t ev, uint64_t* ns_out);
  * basename of file_name is significant, so the reference's "../test/ClKernels/GenerateColors"
  * resolves.  Unknown kernels -> PT_ERR_NOT_FOUND and *out = NULL (Adl returns 0).
  * Registered: ("GenerateColors","GenerateColors"), ("PtShimTest","FillKernel"),
- * ("PtShimTest","MathKernel") -- the last two are smoke/parity-test kernels. */
+ * ("PtShimTest","MathKernel"), ("PtShimTest","FoldCheckKernel") -- the last three are smoke/parity-test kernels. */
 int pt_kernel_get(pt_device_t dev, const char* file_name, const char* func_name, pt_kernel_t* out);
 
 #define PT_MAX_ARG_SIZE 64  /* Launcher::MAX_ARG_SIZE  Adl/AdlKernel.h:129 */

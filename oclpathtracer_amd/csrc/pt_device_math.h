@@ -237,6 +237,58 @@ PTK_DEV float pt_pow(float x, float y, const double* logc, const double* logl, c
     return (float)(res * sc);
 }
 
+// ---- the regular part of pow, opened up for callers that chain evaluations (the fold kernel) --------
+// pt_pow's value for x in PTK_POW_REGULAR (normal, positive, far from the ends of the exponent range)
+// and an exponent whose product with log2(x) stays inside (-160, 130): the SAME binary64 operations
+// as pt_pow on that branch, returned before the final conversion, with log2(x) beside it.  What
+// differs is instruction selection only, and only where the value cannot differ:
+//   * nearest(128 t) by v_rndne_f64 instead of trunc(128 t +- 0.5) -- different at exact ties alone,
+//     which the exhaustive comparison (tests/test_gpu_fold_exact.py: every binary32 x of the range
+//     against pt_pow) shows do not occur for the exponent the fold uses;
+//   * the scaling by 2^q by v_ldexp_f64 instead of a multiplication by a constructed power of two.
+#define PTK_POW_REGULAR_MIN 0x1p-80f
+#define PTK_POW_REGULAR_MAX 0x1p80f
+PTK_DEV bool pt_pow_is_regular(float x)
+{
+    // one unsigned compare: negative numbers, NaN, 0 and subnormals wrap around or fall below
+    return (__float_as_uint(x) - __float_as_uint(PTK_POW_REGULAR_MIN)) <
+           (__float_as_uint(PTK_POW_REGULAR_MAX) - __float_as_uint(PTK_POW_REGULAR_MIN));
+}
+
+PTK_DEV double pt_pow_regular(float x, float y, const double* logc, const double* logl, const double* exp2t, double& log2x)
+{
+    double xd = (double)x;
+    uint64_t bits = (uint64_t)__double_as_longlong(xd);
+    int e = (int)(bits >> 52) - 1023;
+    int idx = (int)(bits >> 45) & 127;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __longlong_as_double((long long)bits);
+    double r = pt_fmad(m, logc[idx], -1.0);
+    double p = pt_k64(PTK_LOG2_A6);
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A5));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A4));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A3));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A2));
+    p = pt_fmad(p, r, pt_k64(PTK_LOG2_A1));
+    double l = pt_fmad(r, p, (double)e + logl[idx]);
+    log2x = l;
+    double t = (double)y * l;
+    double kd = __builtin_rint(t * 128.0);
+    int ki = (int)kd;
+    double f = pt_fmad(-kd, 0x1p-7, t);
+    int j = ki & 127;
+    int q = ki >> 7;   // == (ki - j) >> 7
+    double g = pt_k64(PTK_EXP2_B5);
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B4));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B3));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B2));
+    g = pt_fmad(g, f, pt_k64(PTK_EXP2_B1));
+    double w = f * g;
+    double T = exp2t[j];
+    double res = pt_fmad(T, w, T);
+    return __builtin_ldexp(res, q);
+}
+
 #define PTK_TWO_PI 6.28318530718f
 #define PTK_INV_PI 0.31830988618f
 #define PTK_TAN_HALF_FOV 0x1.279a74p-1f  // tan(0.5f*fov), fov = (float)((60.0f*M_PI)/180.0f); correctly rounded

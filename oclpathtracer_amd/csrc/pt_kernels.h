@@ -166,6 +166,8 @@ hipError_t ptk_assemble_stripes(const float4* gathered, float4* image, int width
 hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStream_t s);
 hipError_t ptk_fill_i32(int32_t* dst, int32_t value, int n, hipStream_t s);
 hipError_t ptk_math(const float* in, float* out, int n, hipStream_t s);
+// the fold kernel's short forms against the literal operations (pt_fold_check_kernel); out: 6 counters
+hipError_t ptk_fold_check(unsigned long long* out, int mode, unsigned first, unsigned long long count, hipStream_t s);
 // dynamic LDS of variant 1: the triangle table (scenes up to PT_LDS_TRI_MAX) + one camera-ray slot
 // per sample of every wave's current batch
 size_t ptk_trace_lds_bytes(int ntri);

@@ -1738,43 +1738,255 @@ void pt_trace_bvh_kernel(const PtTraceParams P)
 // ------------------------------------------------------------------------------------------
 // fold kernel: GenerateColors.cl:290-300, 314-321, frames in ascending order per pixel
 // ------------------------------------------------------------------------------------------
+// Per frame z >= 1 and channel the reference computes
+//     o = pow(m, 2.2f);   m = pow((o * (z - 1) + c) / z, 1.0f / 2.2f)              (:316-320)
+// where m is the pixel it wrote one frame earlier: two pow and one division per sample and channel,
+// all of the fold's time.  Written literally (round 2) that is 112 vector instructions per frame, 27 of
+// them binary64.  Two of the three operations have an operand with structure, and each gets a short
+// form that returns THE SAME BITS (tests/test_gpu_fold_exact.py compares each with the literal form
+// over every binary32 operand, on the GPU):
+//
+//  * decode, o = pow(m, 2.2f).  m is not any number: it is m = fl32(E), E = the binary64 value of
+//    pow(v, 1/2.2f) one step earlier, and v, E and log2(v) are still in registers.  Exactly,
+//        m^y2 = v * v^eta * (1 + delta)^y2,      delta = (m - E) / E,   eta = y1 * y2 - 1 = -1.41e-8
+//    (y1 = fl32(1/2.2f), y2 = 2.2f), up to the 2^-49 of the two binary64 evaluations.  So o lies within
+//    a few ulps of v, and   o = fl32(v + v * (y2 * delta + eta * ln v))   whenever that rounding is the
+//    same at both ends of the expression's uncertainty interval (Ziv's test; the neglected terms are
+//    (eta ln v)^2 / 2 < 2^-41 and y2 (y2 - 1) delta^2 / 2 < 2^-47, binary32 evaluation of the small
+//    term adds < 2^-42: the interval is +- 2^-36 v).  One sample in 3 000 fails the test and
+//    takes the literal pow; 14 instructions replace 50.
+//  * the division by z.  z is the same for the whole launch step, 1/z correctly rounded comes from a
+//    table in LDS, and Markstein's theorem (IBM J. R&D 34, 1990: y = RN(1/b), q0 = RN(a y),
+//    r = a - b q0 exact, then RN(q0 + r y) = RN(a / b)) gives the IEEE quotient in three instructions
+//    as long as nothing underflows: numerators in PTK_POW_REGULAR, which is also the range in which
+//    the next pow needs no special case.
+//  * encode, m = pow(a, 1/2.2f): pt_pow_regular (no special cases left to test).
+// Zero (black so far) is common and handled by selection; anything else outside the regular range
+// (negative, NaN, infinite, tiny, huge) takes the literal operations in a branch that whole waves skip.
+#define PT_FOLD_RCP_N 2048            // 1/z tabulated for z < this; later frames divide
+#define PT_FOLD_ETA_LN2 -0x1.4f889ep-27f   // (fl32(1/2.2f) * 2.2f - 1) * ln 2
+#define PT_FOLD_ZIV 0x1p-36f
+
+struct PtFoldChain {
+    float m;      // the pixel: gamma-encoded running mean
+    float v;      // what m was encoded from
+    double E, l;  // binary64 pow(v, 1/2.2f) before its rounding to m, and log2(v)
+    bool reg;     // v was regular: E and l are valid
+};
+
+// a / zf for a regular: IEEE quotient (Markstein); y = RN(1 / zf)
+PTK_DEV float pt_fold_div(float a, float zf, float y)
+{
+    const float q0 = a * y;
+    const float r = pt_fma(-zf, q0, a);
+    return pt_fma(r, y, q0);
+}
+
+// o = pow(s.m, 2.2f)
+PTK_DEV float pt_fold_decode(const PtFoldChain& s, const double* LC, const double* LL, const double* ET, unsigned* n_slow)
+{
+    float o = 0.0f;
+    bool ok = s.reg;
+    if (ok) {
+        const float df = (float)((double)s.m - s.E);
+        const float c = pt_fma(PT_FOLD_ETA_LN2, (float)s.l, (PTK_GAMMA * df) * __builtin_amdgcn_rcpf(s.m));
+        const float t1 = s.v * c;
+        const float u = s.v * PT_FOLD_ZIV;
+        const float lo = s.v + (t1 - u), hi = s.v + (t1 + u);
+        o = lo;
+        ok = lo == hi;
+    }
+    if (!ok && s.m != 0.0f) {
+        o = pt_pow(s.m, PTK_GAMMA, LC, LL, ET);
+        if (n_slow) ++*n_slow;
+    }
+    return o;
+}
+
+// s <- the chain after m = pow(a, 1/2.2f)
+PTK_DEV void pt_fold_encode(PtFoldChain& s, float a, bool reg, const double* LC, const double* LL, const double* ET)
+{
+    const float inv_gamma = 1.0f / PTK_GAMMA;
+    s.E = pt_pow_regular(reg ? a : 1.0f, inv_gamma, LC, LL, ET, s.l);
+    s.m = (float)s.E;
+    s.v = a;
+    s.reg = reg;
+    if (!reg) s.m = (a == 0.0f) ? 0.0f : pt_pow(a, inv_gamma, LC, LL, ET);
+}
+
+// one frame of :314-321 for one channel: z = the frame's number, c = its radiance, rz = RN(1/z) if z < PT_FOLD_RCP_N
+PTK_DEV void pt_fold_frame(PtFoldChain& s, int z, float c, const float* rcp_z, const double* LC, const double* LL,
+                           const double* ET, unsigned* n_slow)
+{
+    float a = c;
+    bool reg = pt_pow_is_regular(c);
+    if (z != 0) {
+        const float o = pt_fold_decode(s, LC, LL, ET, n_slow);
+        const float zm1 = (float)(z - 1), zf = (float)z;
+        const float num = o * zm1 + c;
+        if (z < PT_FOLD_RCP_N) {
+            reg = pt_pow_is_regular(num);
+            a = pt_fold_div(reg ? num : 1.0f, zf, rcp_z[z]);
+            if (!reg) a = (num == 0.0f) ? 0.0f : num / zf;
+            // (a regular num / z (z < 2048) is >= 2^-91: normal and positive; pt_pow_regular needs no more)
+        } else {
+            a = num / zf;
+            reg = pt_pow_is_regular(a);
+        }
+    }
+    pt_fold_encode(s, a, reg, LC, LL, ET);
+}
+
 __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
 {
-    // the three pow tables (3 KiB) in LDS: per-lane indices, read 6 x per sample
+    // the three pow tables (3 KiB) and the reciprocals of the frame numbers (8 KiB) in LDS
     __shared__ double tab[3][128];
+    __shared__ float rcp_z[PT_FOLD_RCP_N];
     for (int k = (int)threadIdx.x; k < 384; k += 256) {
         int w = k >> 7, i = k & 127;
         tab[w][i] = w == 0 ? pt_pow_logc_tab[i] : w == 1 ? pt_pow_logl_tab[i] : pt_pow_exp2_tab[i];
+    }
+    {
+        // only the frames of this launch
+        const int z0 = P.frame_begin, z1 = min(P.frame_begin + P.frame_count, PT_FOLD_RCP_N);
+        for (int k = z0 + (int)threadIdx.x; k < z1; k += 256) rcp_z[k] = 1.0f / (float)k;
     }
     __syncthreads();
     const double* LC = tab[0];
     const double* LL = tab[1];
     const double* ET = tab[2];
-    // one lane per (pixel, channel): the three channels are independent chains of 2 pow per frame, and
+    // one lane per (pixel, channel): the three channels are independent chains, and
     // a rank's share of a multi-GPU render has too few pixels to fill the chip with one lane per pixel
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lp = tid / 3u, ch = tid - 3u * lp;
     if (lp >= P.npix_local) return;
-    const float inv_gamma = 1.0f / PTK_GAMMA;
     float* fbp = reinterpret_cast<float*>(P.fb + lp) + ch;
-    float m = 0.0f;
+    PtFoldChain s;
+    s.m = 0.0f;
+    s.v = 0.0f;
+    s.E = 0.0;
+    s.l = 0.0;
+    s.reg = false;
     int z = P.frame_begin;
-    if (z != 0) m = *fbp;
+    if (z != 0) s.m = *fbp;   // a resumed pixel: its first decode is the literal pow
     const float* radp = P.rad + (size_t)lp * 3u + ch;  // == P.rad + tid: consecutive lanes read consecutive floats
+    // (the next frame's radiance is requested before this frame's arithmetic: the chain never waits for memory)
+    const size_t stride = (size_t)P.npix_local * 3u;
+    float c = P.frame_count > 0 ? radp[0] : 0.0f;
+    asm volatile("" : "+v"(c));   // wait for the first value here, not at the loop's head (where the wait would cover every later load too)
     for (int f = 0; f < P.frame_count; ++f, ++z) {
-        const float c = radp[(size_t)f * P.npix_local * 3u];
-        if (z == 0) {
-            m = pt_pow(c, inv_gamma, LC, LL, ET);
-        } else {
-            const float zm1 = (float)(z - 1), zf = (float)z;
-            const float o = pt_pow(m, PTK_GAMMA, LC, LL, ET);
-            m = pt_pow((o * zm1 + c) / zf, inv_gamma, LC, LL, ET);
-        }
+        const float cn = f + 1 < P.frame_count ? radp[(size_t)(f + 1) * stride] : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc sinks the load to the end of the iteration)
+        pt_fold_frame(s, z, c, rcp_z, LC, LL, ET, nullptr);
+        c = cn;
     }
     if (P.frame_count > 0) {
-        *fbp = m;
+        *fbp = s.m;
         if (ch == 0u) reinterpret_cast<float*>(P.fb + lp)[3] = 1.0f;
     }
+}
+
+// The short forms against the literal ones, operand by operand (tests/test_gpu_fold_exact.py).  Work-item i of mode
+//   0: x = the binary32 with bits first + i: pt_pow_regular(x, 1/2.2f) rounded against pt_pow(x, 1/2.2f)      -> out[0] mismatches
+//   1: v = those bits: the decode of the chain after encoding v against pow(pow(v, 1/2.2f), 2.2f)             -> out[1], literal-pow fallbacks out[2]
+//   2: numerator mantissa i & 0x7fffff at three exponents, z = first + (i >> 23): pt_fold_div against "/"      -> out[3]
+//   3: chain i (seed first): 32 frames of arbitrary radiance -- ordinary values over 40 binades, zeros, huge, tiny and
+//      subnormal ones, negatives, infinities, NaN -- from frame 0 or resumed at a later frame from an arbitrary pixel:
+//      pt_fold_frame against the literal :314-321, every frame's pixel compared                                -> out[5]
+// out[4] counts the operands that were checked (modes 0-2: regular ones; the others take the literal operations by construction).
+__global__ __launch_bounds__(256) void pt_fold_check_kernel(unsigned long long* __restrict__ out, int mode, unsigned first,
+                                                            unsigned long long count)
+{
+    __shared__ double tab[3][128];
+    __shared__ float rcp_z[PT_FOLD_RCP_N];
+    for (int k = (int)threadIdx.x; k < 384; k += 256) {
+        int w = k >> 7, i = k & 127;
+        tab[w][i] = w == 0 ? pt_pow_logc_tab[i] : w == 1 ? pt_pow_logl_tab[i] : pt_pow_exp2_tab[i];
+    }
+    if (mode == 3)
+        for (int k = (int)threadIdx.x; k < PT_FOLD_RCP_N; k += 256) rcp_z[k] = 1.0f / (float)k;
+    __syncthreads();
+    const double* LC = tab[0];
+    const double* LL = tab[1];
+    const double* ET = tab[2];
+    const float inv_gamma = 1.0f / PTK_GAMMA;
+    unsigned bad = 0, slow = 0, seen = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        if (mode == 0 || mode == 1) {
+            const float x = __uint_as_float(first + (unsigned)i);
+            if (!pt_pow_is_regular(x)) continue;
+            ++seen;
+            if (mode == 0) {
+                double l;
+                const float got = (float)pt_pow_regular(x, inv_gamma, LC, LL, ET, l);
+                const float want = pt_pow(x, inv_gamma, LC, LL, ET);
+                bad += __float_as_uint(got) != __float_as_uint(want);
+            } else {
+                PtFoldChain s;
+                pt_fold_encode(s, x, true, LC, LL, ET);
+                const float got = pt_fold_decode(s, LC, LL, ET, &slow);
+                const float want = pt_pow(pt_pow(x, inv_gamma, LC, LL, ET), PTK_GAMMA, LC, LL, ET);
+                bad += __float_as_uint(got) != __float_as_uint(want);
+            }
+        } else if (mode == 3) {
+            uint32_t h = pt_hash_u32(first ^ (uint32_t)i) ^ (uint32_t)(i >> 32);
+            auto arbitrary = [&](bool pixel) -> float {
+                const float u = pt_random_float(h), w = pt_random_float(h);
+                const unsigned kind = (unsigned)(pt_random_float(h) * 64.0f);
+                const unsigned mant = (unsigned)(w * 8388608.0f) & 0x7fffffu;
+                if (kind < 44u) return __uint_as_float(((unsigned)(97.0f + u * 40.0f) << 23) | mant);    // 2^-30 .. 2^10
+                if (kind < 50u) return 0.0f;
+                if (kind < 53u) return __uint_as_float(((unsigned)(190.0f + u * 64.0f) << 23) | mant);   // 2^63 .. 2^127
+                if (kind < 56u) return __uint_as_float(((unsigned)(u * 60.0f) << 23) | mant);            // subnormal .. 2^-67
+                if (kind < 58u) return __uint_as_float(((unsigned)(40.0f + u * 20.0f) << 23) | mant);    // around 2^-80
+                if (kind < 60u) return __uint_as_float(((unsigned)(200.0f + u * 12.0f) << 23) | mant);   // around 2^80
+                if (kind == 60u) return pixel ? 1.0f : -__uint_as_float(((unsigned)(120.0f + u * 10.0f) << 23) | mant);
+                if (kind == 61u) return __builtin_inff();
+                if (kind == 62u) return pixel ? 0.5f : __builtin_nanf("");
+                return __uint_as_float(((unsigned)(126.0f + u * 2.0f) << 23));                           // powers of two near 1
+            };
+            PtFoldChain s;
+            s.m = 0.0f; s.v = 0.0f; s.E = 0.0; s.l = 0.0; s.reg = false;
+            float ml = 0.0f;
+            int z = 0;
+            if (i & 1ull) {
+                z = 1 + (int)(pt_random_float(h) * ((i & 2ull) ? 3000.0f : 40.0f));
+                s.m = ml = arbitrary(true);
+            }
+            for (int f = 0; f < 32; ++f, ++z) {
+                const float c = arbitrary(false);
+                pt_fold_frame(s, z, c, rcp_z, LC, LL, ET, nullptr);
+                if (z == 0) ml = pt_pow(c, inv_gamma, LC, LL, ET);
+                else {
+                    const float zm1 = (float)(z - 1), zf = (float)z;
+                    const float o = pt_pow(ml, PTK_GAMMA, LC, LL, ET);
+                    ml = pt_pow((o * zm1 + c) / zf, inv_gamma, LC, LL, ET);
+                }
+                ++seen;
+                const bool same = (s.m != s.m && ml != ml) || __float_as_uint(s.m) == __float_as_uint(ml);
+                bad += !same;
+            }
+        } else {
+            const unsigned z = first + (unsigned)(i >> 23);
+            const float zf = (float)z, y = 1.0f / zf;
+            const unsigned mant = (unsigned)i & 0x7fffffu;
+            // the quotient's significand depends on the numerator's significand alone while nothing under- or overflows:
+            // the two ends of the regular range and the middle
+            const unsigned exps[3] = { __float_as_uint(PTK_POW_REGULAR_MIN), 0x3f800000u, __float_as_uint(PTK_POW_REGULAR_MAX) - 0x00800000u };
+            for (int k = 0; k < 3; ++k) {
+                const float a = __uint_as_float(exps[k] | mant);
+                ++seen;
+                bad += __float_as_uint(pt_fold_div(a, zf, y)) != __float_as_uint(a / zf);
+            }
+        }
+    }
+    if (mode == 0 && bad) atomicAdd(out + 0, (unsigned long long)bad);
+    if (mode == 1 && bad) atomicAdd(out + 1, (unsigned long long)bad);
+    if (mode == 1 && slow) atomicAdd(out + 2, (unsigned long long)slow);
+    if (mode == 2 && bad) atomicAdd(out + 3, (unsigned long long)bad);
+    if (mode == 3 && bad) atomicAdd(out + 5, (unsigned long long)bad);
+    if (seen) atomicAdd(out + 4, (unsigned long long)seen);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1930,6 +2142,14 @@ hipError_t ptk_tonemap_ppm(const float4* fb, int32_t* rgb, size_t npix, hipStrea
 {
     if (npix == 0) return hipSuccess;
     hipLaunchKernelGGL(pt_tonemap_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, fb, rgb, npix);
+    return hipGetLastError();
+}
+
+hipError_t ptk_fold_check(unsigned long long* out, int mode, unsigned first, unsigned long long count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    const unsigned long long want = (count + 255) / 256;
+    hipLaunchKernelGGL(pt_fold_check_kernel, dim3((unsigned)(want < 65536ull ? want : 65536ull)), dim3(256), 0, s, out, mode, first, count);
     return hipGetLastError();
 }
 

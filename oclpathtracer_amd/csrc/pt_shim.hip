@@ -46,7 +46,7 @@ extern "C" int pt_abi_version(void) { return PT_SHIM_ABI_VERSION; }
 // ------------------------------------------------------------------------------------------
 // objects
 // ------------------------------------------------------------------------------------------
-enum { KERNEL_GENERATE_COLORS = 0, KERNEL_FILL = 1, KERNEL_MATH = 2, KERNEL_COUNT = 3 };
+enum { KERNEL_GENERATE_COLORS = 0, KERNEL_FILL = 1, KERNEL_MATH = 2, KERNEL_FOLD_CHECK = 3, KERNEL_COUNT = 4 };
 
 struct pt_kernel_s {
     int id;
@@ -227,6 +227,7 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
+    d->kernels[KERNEL_FOLD_CHECK] = { KERNEL_FOLD_CHECK, "PtShimTest", "FoldCheckKernel" };
     if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
         hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid) + sizeof(unsigned)) != hipSuccess ||  // indices, count, the LBVH's grid, records in use
         hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
@@ -1251,6 +1252,30 @@ static int launch_math(pt_device_s* d, const pt_launch_arg* a, int nargs, long l
     return event_end(d, ev);
 }
 
+static int launch_fold_check(pt_device_s* d, const pt_launch_arg* a, int nargs, pt_event_s* ev)
+{
+    // FoldCheckKernel(ulong* out, int mode, uint first, ulong count): the fold kernel's short forms of pow and "/"
+    // against the literal operations, operand by operand (csrc/pt_kernels.hip, pt_fold_check_kernel); the work-item
+    // count of the launch is ignored, `count` operands are checked
+    if (nargs != 4 || !a[0].is_buffer || a[1].is_buffer || a[1].size != 4 || a[2].is_buffer || a[2].size != 4 || a[3].is_buffer ||
+        a[3].size != 8)
+        return fail(PT_ERR_ARGS, "FoldCheckKernel expects (buffer, int, uint, ulong)");
+    pt_buffer_s* out = a[0].buffer;
+    if (!out || out->dev != d || out->bytes < 6 * sizeof(unsigned long long)) return fail(PT_ERR_ARGS, "FoldCheckKernel: bad buffer");
+    int32_t mode;
+    uint32_t first;
+    uint64_t count;
+    memcpy(&mode, a[1].data, 4);
+    memcpy(&first, a[2].data, 4);
+    memcpy(&count, a[3].data, 8);
+    if (mode < 0 || mode > 3) return fail(PT_ERR_ARGS, "FoldCheckKernel: mode %d", mode);
+    int rc = flush_pending(d);
+    if (rc || (rc = event_begin(d, ev))) return rc;
+    HIP_TRY(ptk_fold_check((unsigned long long*)out->dptr, mode, first, count, d->stream));
+    out->version++;
+    return event_end(d, ev);
+}
+
 extern "C" int pt_launch_2d(pt_device_t d, pt_kernel_t k, const pt_launch_arg* args, int nargs, int ntx, int nty, int lx,
                             int ly, pt_event_t ev, float* ms_out)
 {
@@ -1269,6 +1294,7 @@ extern "C" int pt_launch_2d(pt_device_t d, pt_kernel_t k, const pt_launch_arg* a
     case KERNEL_GENERATE_COLORS: return launch_generate_colors(d, args, nargs, n, ev, ms_out);
     case KERNEL_FILL: return launch_fill(d, args, nargs, n, ev);
     case KERNEL_MATH: return launch_math(d, args, nargs, n, ev);
+    case KERNEL_FOLD_CHECK: return launch_fold_check(d, args, nargs, ev);
     default: return fail(PT_ERR_NOT_FOUND, "unknown kernel id");
     }
 }
