@@ -961,9 +961,11 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         if (pdf <= 0.0f) {  // :251
             finished = true;
         } else {
-            s.mask.x = s.mask.x * (color.x * dwin / pdf);  // :253-255
-            s.mask.y = s.mask.y * (color.y * dwin / pdf);
-            s.mask.z = s.mask.z * (color.z * dwin / pdf);
+            float qx = color.x * dwin, qy = color.y * dwin, qz = color.z * dwin;
+            pt_div3(qx, qy, qz, pdf);   // the three IEEE quotients of :253-255
+            s.mask.x = s.mask.x * qx;
+            s.mask.y = s.mask.y * qy;
+            s.mask.z = s.mask.z * qz;
             s.bounce++;
             if (s.bounce >= PT_ARG(max_bounces)) {
                 finished = true;
@@ -1774,13 +1776,8 @@ struct PtFoldChain {
     bool reg;     // v was regular: E and l are valid
 };
 
-// a / zf for a regular: IEEE quotient (Markstein); y = RN(1 / zf)
-PTK_DEV float pt_fold_div(float a, float zf, float y)
-{
-    const float q0 = a * y;
-    const float r = pt_fma(-zf, q0, a);
-    return pt_fma(r, y, q0);
-}
+// a / zf for a regular: IEEE quotient (Markstein, pt_device_math.h); y = RN(1 / zf)
+PTK_DEV float pt_fold_div(float a, float zf, float y) { return pt_div_markstein(a, zf, y); }
 
 // o = pow(s.m, 2.2f)
 PTK_DEV float pt_fold_decode(const PtFoldChain& s, const double* LC, const double* LL, const double* ET, unsigned* n_slow)
@@ -1890,6 +1887,7 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
 //   0: x = the binary32 with bits first + i: pt_pow_regular(x, 1/2.2f) rounded against pt_pow(x, 1/2.2f)      -> out[0] mismatches
 //   1: v = those bits: the decode of the chain after encoding v against pow(pow(v, 1/2.2f), 2.2f)             -> out[1], literal-pow fallbacks out[2]
 //   2: numerator mantissa i & 0x7fffff at three exponents, z = first + (i >> 23): pt_fold_div against "/"      -> out[3]
+//   4: divisor significand first + i against ALL 2^23 numerator significands: pt_fold_div with pt_rcp_fast against "/"  -> out[3]
 //   3: chain i (seed first): 32 frames of arbitrary radiance -- ordinary values over 40 binades, zeros, huge, tiny and
 //      subnormal ones, negatives, infinities, NaN -- from frame 0 or resumed at a later frame from an arbitrary pixel:
 //      pt_fold_frame against the literal :314-321, every frame's pixel compared                                -> out[5]
@@ -1967,6 +1965,18 @@ __global__ __launch_bounds__(256) void pt_fold_check_kernel(unsigned long long* 
                 const bool same = (s.m != s.m && ml != ml) || __float_as_uint(s.m) == __float_as_uint(ml);
                 bad += !same;
             }
+        } else if (mode == 4) {
+            // EVERY pair of significands: divisor 1.b (b = first + i), all 2^23 numerators 1.a; the quotient's significand
+            // depends on nothing else while no operand or intermediate leaves the normal range (the callers' guards)
+            const float b = __uint_as_float(0x3f800000u | ((first + (unsigned)i) & 0x7fffffu));
+            const float y = pt_rcp_fast(b);
+            unsigned nb = 0;
+            for (unsigned a_m = 0; a_m < 0x800000u; ++a_m) {
+                const float a = __uint_as_float(0x3f800000u | a_m);
+                nb += __float_as_uint(pt_fold_div(a, b, y)) != __float_as_uint(a / b);
+            }
+            bad += nb;
+            seen += 1u;   // (divisors; x 2^23 numerators each)
         } else {
             const unsigned z = first + (unsigned)(i >> 23);
             const float zf = (float)z, y = 1.0f / zf;
@@ -1984,7 +1994,7 @@ __global__ __launch_bounds__(256) void pt_fold_check_kernel(unsigned long long* 
     if (mode == 0 && bad) atomicAdd(out + 0, (unsigned long long)bad);
     if (mode == 1 && bad) atomicAdd(out + 1, (unsigned long long)bad);
     if (mode == 1 && slow) atomicAdd(out + 2, (unsigned long long)slow);
-    if (mode == 2 && bad) atomicAdd(out + 3, (unsigned long long)bad);
+    if ((mode == 2 || mode == 4) && bad) atomicAdd(out + 3, (unsigned long long)bad);
     if (mode == 3 && bad) atomicAdd(out + 5, (unsigned long long)bad);
     if (seen) atomicAdd(out + 4, (unsigned long long)seen);
 }

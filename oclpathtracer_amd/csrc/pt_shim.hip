@@ -1268,7 +1268,7 @@ static int launch_fold_check(pt_device_s* d, const pt_launch_arg* a, int nargs, 
     memcpy(&mode, a[1].data, 4);
     memcpy(&first, a[2].data, 4);
     memcpy(&count, a[3].data, 8);
-    if (mode < 0 || mode > 3) return fail(PT_ERR_ARGS, "FoldCheckKernel: mode %d", mode);
+    if (mode < 0 || mode > 4) return fail(PT_ERR_ARGS, "FoldCheckKernel: mode %d", mode);
     int rc = flush_pending(d);
     if (rc || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_fold_check((unsigned long long*)out->dptr, mode, first, count, d->stream));
