@@ -67,3 +67,68 @@ def test_chains_on_arbitrary_radiance_equal_the_literal_fold(device):
     res = _check(device, 3, 20261004, 1 << 22)
     assert res[4] == 32 << 22
     assert res[5] == 0
+
+
+@pytest.mark.parametrize("case", ["tiny", "huge", "mixed", "nonfinite"])
+def test_fold_on_extreme_radiance_matches_the_oracle(device, oracle, cornell, case):
+    """The same through the product path and against the CPU oracle: emitters whose radiance puts the running mean outside
+    the range of the short forms (below 2^-80, above 2^80, negative sums clamped at :260, infinities and NaN), rendered
+    from frame 0 and resumed from pixels holding arbitrary values."""
+    from conftest import assert_fb_equal
+    from test_gpu_parity import _render_gpu
+
+    tris, mats = cornell
+    mats = mats.copy()
+    em = {"tiny": [3e-27, 1e-33, 2e-25, 0.0, 4e-38, 1e-30],
+          "huge": [3e25, 1e30, 2e24, 7e28, 0.0, 1e33],
+          "mixed": [1e-27, 2e26, 0.5, -3.0, 0.0, 1e-40],
+          "nonfinite": [np.inf, 1.0, np.nan, -np.inf, 0.0, 2.0]}[case]
+    for i in range(len(mats)):
+        e = np.float32(em[i % len(em)])
+        mats[i]["emissive"] = (e, e * np.float32(0.5), e * np.float32(2.0), 1.0)
+    W, H, frames = 48, 32, 6
+    with np.errstate(all="ignore"):
+        want = oracle.render(tris, mats, W, H, frames)
+        got = _render_gpu(device, tris, mats, W, H, frames)
+        assert_fb_equal(got, want, "extreme radiance (%s), from frame 0" % case)
+        rng = np.random.default_rng(3)
+        junk = (2.0 ** rng.uniform(-140, 120, (W * H, 4))).astype(np.float32)
+        junk[rng.random((W * H, 4)) < 0.1] = 0.0
+        junk[7, 1], junk[9, 2], junk[11, 0], junk[13, 1] = np.inf, np.nan, -1.5, 1e-45
+        want = oracle.render(tris, mats, W, H, 4, frame_begin=3, fb=junk.copy())
+        got = _render_gpu(device, tris, mats, W, H, 4, frame_begin=3, fb_init=junk)
+        assert_fb_equal(got, want, "extreme radiance (%s), resumed at frame 3" % case)
+    if case in ("tiny", "huge"):
+        # the scene must really drive the mean out of the regular range
+        fin = got[:, :3][np.isfinite(got[:, :3]) & (got[:, :3] > 0)]
+        enc = fin.astype(np.float64) ** 2.2
+        assert ((enc < 2.0 ** -80) | (enc > 2.0 ** 80)).mean() > 0.2
+
+
+@pytest.mark.parametrize("case", ["albedo", "roughness"])
+def test_throughput_quotients_outside_the_short_forms_range_match_the_oracle(device, oracle, cornell, case):
+    """color * dot / pdf (:253-255) goes through one exact reciprocal and Markstein's correction while the three numerators
+    and the pdf are in a guarded range (csrc/pt_device_math.h, pt_div3), through the generic division otherwise: materials
+    whose albedo (numerators: tiny, huge, zero, negative, NaN) or roughness (pdf: 1e13 and beyond, 0/0) leave that range."""
+    from conftest import assert_fb_equal
+    from oclpathtracer_amd import scene
+    from test_gpu_parity import _render_gpu
+
+    tris, mats = cornell
+    mats = mats.copy()
+    if case == "albedo":
+        vals = [1e-25, 3e22, 0.0, -0.5, 1e-38, np.nan, 0.7, 2e19]
+        for i in range(len(mats)):
+            a = np.float32(vals[i % len(vals)])
+            mats[i]["albedo"] = (a, a * np.float32(3.0), np.float32(0.6), 1.0)
+    else:
+        vals = [1e-7, 3e-6, 0.0, 1e-9, 0.02, 1e-5]
+        for i in range(len(mats)):
+            mats[i]["type"] = scene.SPECULAR
+            mats[i]["roughness"] = np.float32(vals[i % len(vals)])
+    W, H, frames = 64, 40, 4
+    with np.errstate(all="ignore"):
+        want, st = oracle.render(tris, mats, W, H, frames, want_stats=True)
+        got = _render_gpu(device, tris, mats, W, H, frames)
+    assert_fb_equal(got, want, "quotients outside the guarded range (%s)" % case)
+    assert st["rays"] > 2 * W * H * frames     # paths do continue past the first hit
