@@ -580,7 +580,11 @@ PTK_DEV void pt_pass2_finish(const PtPrepTriangle* tris, const f3& o, const f3& 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            tl.keys[lane] = ~0ull;
+            // (the constant is made here: hoisted out of the bounce loop it was the register pair the 64-VGPR kernel spilled,
+            // and its reload from scratch waited for every store in flight)
+            unsigned long long ones;
+            asm volatile("v_mov_b64 %0, -1" : "=v"(ones));
+            tl.keys[lane] = ones;
             const unsigned long long key = tl.kbest;
             const float kt = __uint_as_float((unsigned)(key >> 32));
             const int ki = (int)((unsigned)key >> 6);
@@ -862,7 +866,7 @@ struct PtPath {
 // ---- shade one bounce of a live path (:229-258); on path end store its radiance --------------------
 template <bool DET_BOUNDED, bool LATE>
 PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax, float hu, float hv, int hidx,
-                      unsigned& n_rays, unsigned& n_samples, unsigned long long* sub = nullptr)
+                      unsigned long long* sub = nullptr)
 {
     const pt_kargs_p K = pt_kargs();  // tris, mats, nmat, max_bounces, rad, npix_local: read here, not kept in SGPRs
 #if PT_STAMPS == 2
@@ -874,7 +878,6 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
     (void)sub;
     PT_SUB(q0);
     bool finished = false;
-    n_rays++;
     if (hidx < 0) {
         const float bg = pt_max(0.45f, 0.0f);
         s.L = add3(s.L, scale3(s.mask, bg));  // :235
@@ -989,7 +992,6 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         v.y = pt_max(s.L.y, 0.0f);
         v.z = pt_max(s.L.z, 0.0f);
         *reinterpret_cast<pt_f3v*>(out) = v;  // one 12-byte store (global_store_dwordx3)
-        n_samples++;
         alive = false;
     }
 #if PT_STAMPS == 2
@@ -999,15 +1001,13 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
 #undef PT_SUB
 }
 
+// (n_rays, n_samples: wave-uniform tallies kept in SGPRs -- popcounts of the lanes that shaded / finished; as per-lane counters they
+// were the two registers the 64-VGPR kernel spilled, and the reload in the store block waited for the radiance store itself)
 PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n_rays, unsigned n_samples)
 {
     if (!P.stats) return;
     // wave reduction of the work counters, one atomic pair per wave
-    unsigned long long r = n_rays, s = n_samples;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        s += __shfl_down(s, off);
-    }
+    const unsigned long long r = n_rays, s = n_samples;
     if (lane == 0) {
         atomicAdd(&P.stats[0], s);
         atomicAdd(&P.stats[1], r);
@@ -1244,11 +1244,14 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 #endif
 
         PT_STAMP(t2);
+        const unsigned long long shaded = __ballot(alive);
+        n_rays += (unsigned)__popcll(shaded);
 #if PT_STAMPS == 2
-        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples, c_sub);
+        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx, c_sub);
 #else
-        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx, n_rays, n_samples);
+        if (alive) pt_shade<DET_BOUNDED, true>(P, s, alive, tmax, hu, hv, hidx);
 #endif
+        n_samples += (unsigned)__popcll(shaded & ~__ballot(alive));   // (a path leaves pt_shade dead only when it has finished)
 #if PT_STAMPS
         PT_STAMP(t3);
         c_regen += t1 - t0; c_loop += t2 - t1; c_shade += t3 - t2; c_iters++;
@@ -1683,7 +1686,10 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (TALLY) ++c_tsteps;
                 pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, s.o, s.d, n_recs);
             }
-            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx, n_rays, n_samples);
+            const unsigned long long shaded = __ballot(alive && !trav);
+            n_rays += (unsigned)__popcll(shaded);
+            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx);
+            n_samples += (unsigned)__popcll(shaded & ~__ballot(alive));
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
             const bool start = alive && !trav;
             if (__ballot(start) != 0ull) {
