@@ -146,7 +146,7 @@ def parse_args(argv=None):
     ap.add_argument("--stripe-rows", type=int, default=4,
                     help="rows per image stripe of the N-rank split (4: the ranks' shares of configs[2] are equal to 1 %%; 16: 2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] / configs[4] legs of extra.configs")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] / configs[3] / configs[4] legs of extra.configs")
     ap.add_argument("--quad-filter", type=int, default=0, help="PT_OPT_QUAD_FILTER (A/B timing): 0 strongest, 1 none, 4 packed")
     ap.add_argument("--accel", type=int, default=0, help="PT_OPT_ACCEL: 0 auto (LBVH from 512 triangles), 1 brute force, 2 LBVH")
     ap.add_argument("--soup", type=int, default=None, help="render the synthetic N-triangle soup of BASELINE configs[4] (Cornell box + "
@@ -530,6 +530,14 @@ def extra_configs(dev, lib, shim, scene, adl, fence, args):
     img.release()
     res["configs[1]"] = {"workload": "cornellbox.bin 512x512, 64 spp, depth 2", "value": 512 * 512 * 64 * steps / dt / 1e6,
                          "unit": "Msamples/s", "steps": steps, "ms_per_step": dt / steps * 1e3}
+    # configs[3]'s image on ONE GPU (BASELINE names 8 + gather): cornellbox 2048x2048, 1024 spp, depth 16; one timed render
+    img = StripeImage(dev, tris, mats, 2048, 2048, want_stats=True)
+    img.render(8, frame_begin=0, max_bounces=16)
+    img.gather()
+    dt = time_render(img, fence, 1, 0, 1024, 16)
+    img.release()
+    res["configs[3]"] = {"workload": "cornellbox.bin 2048x2048, 1024 spp, depth 16, 1 GPU (BASELINE names 8 + gather)",
+                         "value": 2048 * 2048 * 1024 / dt / 1e6, "unit": "Msamples/s", "steps": 1, "ms_per_step": dt * 1e3}
     # configs[4] scene on ONE GPU at full size: 10^6-triangle soup, 1024x1024, 256 spp, depth 16, LBVH
     tris, mats = scene.make_soup(1_000_000)
     img = StripeImage(dev, tris, mats, 1024, 1024, want_stats=True)
