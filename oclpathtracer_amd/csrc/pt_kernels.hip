@@ -1774,6 +1774,7 @@ void pt_trace_bvh_kernel(const PtTraceParams P)
 #define PT_FOLD_RCP_N 2048            // 1/z tabulated for z < this; later frames divide
 #define PT_FOLD_ETA_LN2 -0x1.4f889ep-27f   // (fl32(1/2.2f) * 2.2f - 1) * ln 2
 #define PT_FOLD_ZIV 0x1p-36f
+#define PT_FOLD_NUM_MIN 0x1p-69f       // PTK_POW_REGULAR_MIN * PT_FOLD_RCP_N
 
 struct PtFoldChain {
     float m;      // the pixel: gamma-encoded running mean
@@ -1828,10 +1829,14 @@ PTK_DEV void pt_fold_frame(PtFoldChain& s, int z, float c, const float* rcp_z, c
         const float zm1 = (float)(z - 1), zf = (float)z;
         const float num = o * zm1 + c;
         if (z < PT_FOLD_RCP_N) {
-            reg = pt_pow_is_regular(num);
+            // numerators in [2^-69, 2^80): the quotient by z < 2^11 is then regular itself -- inside the range over which the
+            // encode and the next decode were compared with the literal pow exhaustively
+            reg = (__float_as_uint(num) - __float_as_uint(PT_FOLD_NUM_MIN)) < (__float_as_uint(PTK_POW_REGULAR_MAX) - __float_as_uint(PT_FOLD_NUM_MIN));
             a = pt_fold_div(reg ? num : 1.0f, zf, rcp_z[z]);
-            if (!reg) a = (num == 0.0f) ? 0.0f : num / zf;
-            // (a regular num / z (z < 2048) is >= 2^-91: normal and positive; pt_pow_regular needs no more)
+            if (!reg) {
+                a = (num == 0.0f) ? 0.0f : num / zf;
+                reg = pt_pow_is_regular(a);
+            }
         } else {
             a = num / zf;
             reg = pt_pow_is_regular(a);
