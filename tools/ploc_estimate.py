@@ -6,7 +6,13 @@ internal nodes a random ray enters -- for (a) the Morton radix tree the library 
 (Meister & Bittner 2018: mutual nearest neighbours by merged surface area within a window of the Morton order), on the ~51 000
 triangles of the soup whose centres lie in a cube of side 2 (the soup's own density and triangle sizes).
 usage: python tools/ploc_estimate.py [side]      -> profiles/r03/lbvh_steps.txt"""
-sys.path.insert(0, __file__.rsplit('/', 2)[0])
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oclpathtracer_amd import scene
 t,m = scene.make_soup(1_000_000)
 p1=t['p1'][36:,:3]; p2=t['p2'][36:,:3]; p3=t['p3'][36:,:3]
