@@ -89,7 +89,9 @@ PTK_DEV float pt_sqrt(float x)
 // against the generic division on the MI355X (tools/div_exhaustive.py, profiles/r03/div_exhaustive.txt: 7.04e13
 // pairs, 0 mismatches); exponents do not matter while no operand or intermediate leaves the normal range, which
 // the guards below ensure: b in [2^-26, 2^40) (inside pt_rcp_fast's exact range), every numerator +0 or in
-// [2^-60, 2^60) (so q0 is in (2^-100, 2^86) and r, a multiple of 2^-107 at least, is exact).  Anything else --
+// [2^-60, 2^60) (so q0 is in (2^-100, 2^86) and r, a multiple of 2^-107 at least, is formed without underflow).  (The textbook
+// theorem wants a faithful q0, which makes r exact; RN(a RN(1/b)) can be 1.5 ulp off when a < b, and r is then rounded -- one
+// pair in ~700 -- with the quotient still correct: the claim rests on the exhaustive run, not on the theorem.)  Anything else --
 // negative, NaN, infinite, tiny, huge -- takes the generic division.
 PTK_DEV float pt_div_markstein(float a, float b, float y)
 {

@@ -1764,10 +1764,10 @@ void pt_trace_bvh_kernel(const PtTraceParams P)
 //    term adds < 2^-42: the interval is +- 2^-36 v).  One sample in 3 000 fails the test and
 //    takes the literal pow; 14 instructions replace 50.
 //  * the division by z.  z is the same for the whole launch step, 1/z correctly rounded comes from a
-//    table in LDS, and Markstein's theorem (IBM J. R&D 34, 1990: y = RN(1/b), q0 = RN(a y),
-//    r = a - b q0 exact, then RN(q0 + r y) = RN(a / b)) gives the IEEE quotient in three instructions
-//    as long as nothing underflows: numerators in PTK_POW_REGULAR, which is also the range in which
-//    the next pow needs no special case.
+//    table in LDS, and Markstein's sequence (IBM J. R&D 34, 1990: y = RN(1/b), q0 = RN(a y),
+//    r = fma(-b, q0, a), q = fma(r, y, q0)) gives the IEEE quotient in three instructions (checked over every
+//    pair of significands: pt_device_math.h, pt_div3) as long as nothing underflows: numerators in
+//    [PT_FOLD_NUM_MIN, 2^80), whose quotient is in the range where the next pow needs no special case.
 //  * encode, m = pow(a, 1/2.2f): pt_pow_regular (no special cases left to test).
 // Zero (black so far) is common and handled by selection; anything else outside the regular range
 // (negative, NaN, infinite, tiny, huge) takes the literal operations in a branch that whole waves skip.
