@@ -62,7 +62,9 @@ for seed in range(first, first + count):
         assert gst["rays"] == rays, (gst["rays"], rays)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH seed %d kind %d ntri %d %dx%d f%d d%d ranks %d/%d stripe %d opts %s: %s" % (seed, kind, len(tris), W, H, frames, depth, rank, n_ranks, stripe, opts, str(e)[:300]))
-print("fuzz: %d cases from seed %d, %d mismatches, %.1f s" % (count, first, bad, time.time() - t0))
+        print("MISMATCH seed %d kind %d ntri %d %dx%d f%d d%d ranks %d/%d stripe %d opts %s: %s" % (seed, kind, len(tris), W, H, frames, depth, rank, n_ranks, stripe, opts, str(e)[:300]), flush=True)
+    if (seed - first) % 250 == 249:   # (a line now and then: a run that prints nothing for minutes is taken to be hung)
+        print("  ... %d cases, %d mismatches, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+print("fuzz: %d cases from seed %d, %d mismatches, %.1f s" % (count, first, bad, time.time() - t0), flush=True)
 adl.DeviceUtils.deallocate(dev)
 sys.exit(1 if bad else 0)
