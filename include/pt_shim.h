@@ -14,8 +14,11 @@
  *   - handles are opaque.  Calls on one device handle are not thread-safe (the reference
  *     is single-threaded, one in-order queue per device: Adl/CL/AdlCL.cpp:215); different
  *     handles may be driven from different threads / processes (one per GPU).
- *   - all device work of a handle is enqueued on ONE stream in call order
- *     (= the reference's in-order cl_command_queue).
+ *   - all device work of a handle takes effect in call order, as on the reference's in-order
+ *     cl_command_queue.  Everything but the fused renderer is enqueued on ONE stream (the handle's);
+ *     pt_render_frames runs its trace / fold launches on two internal streams ("lanes") so that the
+ *     next trace launch fills the machine while the current one drains, and the handle's stream is
+ *     ordered behind them (by events, never a host wait) as soon as any other call needs its results.
  */
 #ifndef PT_SHIM_H
 #define PT_SHIM_H
@@ -27,7 +30,10 @@
 extern "C" {
 #endif
 
-#define PT_SHIM_ABI_VERSION 1
+/* 2: PT_ERR_TRAVERSAL, PT_OPT_BVH_STACK_LIMIT, PT_OPT_RENDER_LANES, PT_STAT_BVH_*, pt_assemble_stripes_on, the staging ring
+ *    (pt_device_reserve_staging, pt_device_workspace_memory), device-side hand-overs (pt_device_wait_stream, pt_device_wait_hip_event,
+ *    pt_event_wait_on), pt_profile_query_union; option 3 (a kernel-variant switch of version 1) is accepted and ignored */
+#define PT_SHIM_ABI_VERSION 2
 
 enum pt_status {
     PT_OK = 0,
@@ -38,11 +44,15 @@ enum pt_status {
     PT_ERR_NOT_FOUND = 5,  /* unknown kernel (Adl: getKernel returns 0)               */
     PT_ERR_ARGS = 6,       /* launch arguments do not match the kernel's signature    */
     PT_ERR_RANGE = 7,      /* offset/size outside a buffer                            */
-    PT_ERR_TRAVERSAL = 8   /* an LBVH search was cut short (stack capacity or step budget): the render's pixels
-                              may be wrong and must be discarded.  The reference's brute force
-                              (GenerateColors.cl:137-154) cannot skip a triangle, so this is an error, never a
-                              silent approximation; it cannot occur with a hierarchy the library built
-                              (csrc/pt_kernels.hip, PT_BVH_STACK) unless PT_OPT_BVH_STACK_LIMIT lowers the stack */
+    PT_ERR_TRAVERSAL = 8   /* an LBVH search was cut short (stack capacity or step budget): the pixels of the renders
+                              enqueued since the last successful observation may be wrong and must be discarded.  The
+                              reference's brute force (GenerateColors.cl:137-154) cannot skip a triangle, so this is an
+                              error, never a silent approximation; it cannot occur with a hierarchy the library built
+                              (csrc/pt_kernels.hip, PT_BVH_STACK) unless PT_OPT_BVH_STACK_LIMIT lowers the stack.
+                              Renders are asynchronous, so the error is DEFERRED: the kernels raise a sticky word in
+                              host-visible memory and the first call that observes the device afterwards reports it --
+                              pt_sync, pt_event_wait / pt_event_elapsed_ns, a blocking pt_buffer_map, pt_profile_query,
+                              or the next pt_render_frames (which then renders nothing).  Reporting clears the word. */
 };
 
 typedef struct pt_device_s* pt_device_t;
@@ -79,6 +89,18 @@ uint64_t pt_device_max_alloc(pt_device_t dev);   /* Device::getMaxAllocationSize
 uint64_t pt_device_mem_size(pt_device_t dev);    /* Device::getMemSize           */
 uint64_t pt_device_used_memory(pt_device_t dev); /* Device::getUsedMemory  (Adl.h:168) */
 uint64_t pt_device_peak_memory(pt_device_t dev); /* Device::getPeakMemory  (Adl.h:170) */
+/* Device memory the handle holds for ITSELF (not counted by pt_device_used_memory, which is the caller's buffers as in the
+ * reference): the radiance staging ring, the prepared scene, the LBVH, the primary-ray masks, the side tables. */
+uint64_t pt_device_workspace_memory(pt_device_t dev);
+/* The fused renderer stages path radiance (12 B per sample) between its trace and fold kernels in a ring of TWO equal slots,
+ * allocated ONCE per device handle: `bytes` is the size of the whole ring (0 = the default, 2 x 192 MiB: sixteen 1024^2
+ * frames per slot).  pt_render_frames walks its frames through the ring in chunks of as many whole frames as a slot holds
+ * and, once the ring exists, neither allocates, frees nor waits for the device.  Called implicitly with 0 by the first
+ * render; calling it again waits for the device and replaces the ring.  An image of which ONE frame does not fit a slot
+ * (more than 16.7 M pixels with the default) makes the render grow the ring to fit -- the only allocation a render can
+ * still make; reserve enough beforehand to avoid it.  No reference counterpart (the reference keeps no staging: one launch
+ * per frame, 32 B of framebuffer traffic per sample, GenerateColors.cl:314-321). */
+int pt_device_reserve_staging(pt_device_t dev, size_t bytes);
 int pt_device_num_cus(pt_device_t dev);          /* DeviceUtils::getNCUs               */
 
 /* Plumbing, no reference counterpart: run this handle's work on an existing hipStream_t
@@ -89,6 +111,15 @@ int pt_device_num_cus(pt_device_t dev);          /* DeviceUtils::getNCUs        
 #define PT_STREAM_LEGACY ((void*)1)
 int pt_device_set_stream(pt_device_t dev, void* hip_stream);
 void* pt_device_get_stream(pt_device_t dev);
+/* Device-side hand-overs for a caller that keeps the handle on its OWN stream (what the N-rank driver does: renders of
+ * consecutive images then overlap, which a shared stream would serialise).  No reference counterpart.
+ *   pt_device_wait_stream    : the handle's later work starts after everything enqueued so far on hip_stream (a hipStream_t)
+ *   pt_device_wait_hip_event : ... after a hipEvent_t the caller has recorded (e.g. torch.cuda.Event.cuda_event)
+ *   pt_event_wait_on         : work enqueued later on hip_stream starts after the call the event was passed to has completed
+ * None of them blocks the host. */
+int pt_device_wait_stream(pt_device_t dev, void* hip_stream);
+int pt_device_wait_hip_event(pt_device_t dev, void* hip_event);
+int pt_event_wait_on(pt_event_t ev, void* hip_stream);
 
 /* DeviceUtils::waitForCompletion(device) -> clFinish : Adl/Adl.cpp:210-213, AdlCL.cpp:282-285.
  * NOTE: with frame batching enabled (pt_device_set_option) this does not force deferred
@@ -112,7 +143,8 @@ enum pt_option {
     /* Device::toggleProfiling(PROFILE_RETURN_TIME) (Adl.h:171): launches synchronise and
      * return their duration in ms (AdlKernelUtilsCL.cpp:470-487). */
     PT_OPT_PROFILE_RETURN_TIME = 2,
-    /* (3 is not assigned: it selected between trace-kernel variants until only one was left) */
+    /* (3 selected between trace-kernel variants until only one was left: values 0 and 1 are accepted and ignored) */
+    PT_OPT_RESERVED_3 = 3,
     /* conservative pass-1 filter of the closest-hit search, for A/B timing and parity tests:
      * 0 = the strongest the uploaded scene allows, 1..3 = independent triangles (pt_tri_pass1),
      * 4 = the packed shared-u filter when the scene is made of (a,b,c),(c,d,a) quads (two quads per
@@ -135,9 +167,19 @@ enum pt_option {
      * parity tests).  Identical pixels either way. */
     PT_OPT_PRIMARY_MASKS = 7,
     /* test hook of the LBVH's overflow report: the number of stack entries a ray's search may use (1..64; default 64,
-     * which no hierarchy built by the library can exceed).  A search that needs more sets a sticky device flag and the
-     * render returns PT_ERR_TRAVERSAL.  LBVH renders synchronise with the device before returning to read that flag. */
-    PT_OPT_BVH_STACK_LIMIT = 8
+     * which no hierarchy built by the library can exceed).  A search that needs more raises the sticky word behind
+     * PT_ERR_TRAVERSAL (reported by the next call that observes the device; no render waits for the device to read it). */
+    PT_OPT_BVH_STACK_LIMIT = 8,
+    /* streams ("lanes") consecutive renders alternate between: 2 (default) = the first trace launch of render k+1 fills the
+     * machine while the last launch of render k runs its paths out (about 0.3 ms of falling lane use,
+     * profiles/r03/launch_overhead.txt), folds ordered by events so that every pixel folds its frames in ascending order
+     * (GenerateColors.cl:314-321); 1 = one stream, every launch waits for the previous one (A/B timing).  Identical pixels. */
+    PT_OPT_RENDER_LANES = 9,
+    /* 1 (default): the trace launches of a render are CHECKPOINTED -- a launch ends the moment its work queue has handed out
+     * the last batch, every wave saving the paths it still holds, and the render's next launch resumes them -- so that walking
+     * a render through the bounded staging ring in many short launches costs what one long launch costs; 0 = every launch
+     * runs its paths out (A/B timing; always the case for LBVH renders).  Identical pixels either way. */
+    PT_OPT_CHECKPOINT = 10
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);
@@ -225,7 +267,9 @@ int pt_launch_2d(pt_device_t dev, pt_kernel_t kernel, const pt_launch_arg* args,
 /* ---- the fused hot path -------------------------------------------------------------------
  * One call = frames [frame_begin, frame_begin+frame_count) of GenerateColors
  * (test/ClKernels/GenerateColors.cl:302-322) over this device's share of the image,
- * bit-identical to frame_count successive reference launches.
+ * bit-identical to frame_count successive reference launches.  Asynchronous: the call returns when the work is enqueued;
+ * `ev` (may be NULL) completes when the framebuffer holds the last frame.  Consecutive calls overlap on the device as far as
+ * their data allows (the folds of all calls form one chain, so renders into the same framebuffer fold in call order).
  *
  * Image sharding: the image's rows are dealt to n_ranks devices in stripes
  * of stripe_rows rows, round-robin; this device (rank) renders the rows r with
@@ -257,6 +301,7 @@ enum {
      * triangle per participating lane) */
     PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_STEPS = 4 /* node phases */, PT_STAT_BVH_TRI_STEPS = 5,
     PT_STAT_BVH_MAX_STACK = 6 /* the deepest traversal stack any ray needed (a maximum, not a sum; capacity: 64) */,
+    PT_STAT_CARRIED = 7 /* samples (paths under way + samples not yet started) that checkpointed launches handed to their successors */,
     PT_STAT_WORDS = 8
 };
 
@@ -273,6 +318,10 @@ int pt_render_frames(pt_device_t dev, pt_buffer_t triangles, pt_buffer_t materia
 enum { PT_PROF_TRACE = 0, PT_PROF_FOLD = 1, PT_PROF_KINDS = 2 };
 int pt_profile_enable(pt_device_t dev, int on);
 int pt_profile_query(pt_device_t dev, int kind, double* total_ms, uint64_t* launches);
+/* The time during which AT LEAST ONE launch of the kind was executing (the union of the launches' [start, stop] intervals):
+ * with PT_OPT_RENDER_LANES 2 consecutive trace launches overlap -- the next one's first workgroups start while the previous
+ * one's last paths drain -- so the sum of their durations counts that time twice; the union is the machine time they took. */
+int pt_profile_query_union(pt_device_t dev, int kind, double* union_ms);
 int pt_profile_reset(pt_device_t dev);
 
 /* Scatter the gathered per-rank local framebuffers (n_ranks slabs of slab_rows x width

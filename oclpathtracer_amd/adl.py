@@ -110,6 +110,23 @@ class Device:
     def getPeakMemory(self) -> int:
         return self._lib.pt_device_peak_memory(self._h)
 
+    def getWorkspaceMemory(self) -> int:
+        """Device memory the handle holds for itself (staging ring, prepared scene, LBVH, masks): no Adl counterpart."""
+        return self._lib.pt_device_workspace_memory(self._h)
+
+    def reserveStaging(self, nbytes: int = 0) -> None:
+        """Size the renderer's radiance staging ring once (0 = default); renders then never allocate (pt_device_reserve_staging)."""
+        shim.check(self._lib.pt_device_reserve_staging(self._h, int(nbytes)))
+
+    def waitStream(self, hip_stream: int) -> None:
+        """Later work of this device starts after what is enqueued on ``hip_stream`` (device-side wait; ``torch.cuda.Stream.cuda_stream``;
+        torch's default stream reports 0 = the legacy default stream, PT_STREAM_LEGACY)."""
+        shim.check(self._lib.pt_device_wait_stream(self._h, ctypes.c_void_p(int(hip_stream) or shim.PT_STREAM_LEGACY)))
+
+    def waitHipEvent(self, hip_event: int) -> None:
+        """Later work of this device starts after a recorded hipEvent_t (``torch.cuda.Event.cuda_event``)."""
+        shim.check(self._lib.pt_device_wait_hip_event(self._h, ctypes.c_void_p(int(hip_event))))
+
     def toggleProfiling(self, profile_type: int) -> None:
         on = 1 if (profile_type & Device.PROFILE_RETURN_TIME) else 0
         shim.check(self._lib.pt_device_set_option(self._h, shim.PT_OPT_PROFILE_RETURN_TIME, on))
@@ -194,6 +211,10 @@ class SyncObject:
         if r < 0:
             shim.check(shim.PT_ERR_HIP)
         return bool(r)
+
+    def waitOnStream(self, hip_stream: int) -> None:
+        """Work enqueued later on ``hip_stream`` starts after this event (device-side wait; no Adl counterpart)."""
+        shim.check(self.m_device._lib.pt_event_wait_on(self._h, ctypes.c_void_p(int(hip_stream) or shim.PT_STREAM_LEGACY)))
 
     def getExecutionTimeNanoseconds(self) -> int:
         ns = ctypes.c_uint64()

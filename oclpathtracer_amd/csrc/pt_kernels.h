@@ -88,17 +88,24 @@ static_assert(sizeof(PtLeafTri) == 64, "leaf record layout");
 struct PtTraceParams {
     const PtPrepTriangle* tris;
     const PtRawMaterial* mats;
-    float* rad;                   // [chunk_frames][npix_local][3] path radiance max(L,0), 12 bytes per sample
-    unsigned int* batch_counter;  // zeroed before the launch
+    float* rad;                   // the staging RING's two slots, [frames per slot][npix_local][3] path radiance max(L,0) each, 12 bytes per
+    float* rad1;                  // sample.  A path's `fl` is its frame counted from the render's first (frame_begin - chunk_f0 is that frame's
+                                  // absolute number); chunk c of the render is frames [c S, (c + 1) S) and goes to slot (c + ring_phase / S) % 2,
+                                  // so a path CARRIED into the next launch (below) still stores to its own chunk's slot
+    unsigned int* batch_counter;  // the work queue (two cache lines, PT_QUEUE_STOP_WORD); zero at the launch (the fold kernel that follows the trace launch on its stream resets it: PtFoldParams::reset_counter)
     unsigned long long* stats;    // may be null: [0] samples, [1] rays
     int32_t width, height;
     float inv_width, inv_height, aspect;  // 1.0f / W, 1.0f / H, (float)W / (float)H (IEEE, host-computed: GenerateColors.cl:266-267)
     int32_t frame_begin;          // first frame of this chunk (global frame index)
     int32_t frame_count;          // frames in this chunk
+    uint32_t chunk_f0;            // ... and that first frame counted from the render's first (a multiple of the frames per ring slot)
+    uint32_t slot_frames;         // S: frames per ring slot = frames per chunk (the render's last chunk may be shorter)
+    uint32_t ring_phase;          // 0 or S: which slot the render's first chunk uses
+    uint32_t ring_magic;          // floor(2^32 / 2S) + 1: (fl + ring_phase) % 2S by one v_mul_hi_u32 (exact below 65 536)
     int32_t max_bounces, ntri, nmat;
     int32_t stripe_rows, n_ranks, rank;
     uint32_t npix_local;
-    uint32_t batches_per_frame, total_batches;
+    uint32_t batches_per_frame, total_batches;   // total_batches: those of this launch that come off the dynamic queue
     uint32_t batch;               // samples per work-queue grab: 64, 128 or 256 (<= PT_TRACE_BATCH)
     float quad_delta1;            // quad mode 2 (pt_quad2_pass1): slack of the shared-u bounds
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
@@ -113,15 +120,33 @@ struct PtTraceParams {
     int32_t nbig;
     const uint2* pmask;           // quad mode 3, <= 64 triangles: per local pixel the primary rays' candidate masks of the two
                                   // 32-triangle chunks (pt_primary_mask_kernel); null = run pass 1 for primary rays too
-    unsigned int* bvh_flags;      // accel = BVH: one device word of sticky PT_BVH_FLAG_* bits (a search was cut short), zeroed by the host
+    unsigned int* bvh_flags;      // accel = BVH: the sticky word a search that was cut short raises (PT_BVH_FLAG_* bits): host memory mapped into
+                                  //              the device's address space, written with plain system-scope stores, read and cleared by the host
     int32_t bvh_stack_limit;      //              stack entries a lane may use, <= PT_BVH_STACK (lower only to test the overflow report)
+    // CHECKPOINTED launches (table trace kernels): a launch with carry_out set ends the moment its work queue has
+    // handed out the last batch -- every wave, at its next fresh-phase boundary, stores what it still holds (its live paths,
+    // the unstarted rest of its batch) to its region of `carry` and exits -- and the next launch of the render (carry_in_waves = the grid of this one, in
+    // waves) resumes them beside its own work: no launch but a render's last (carry_out = 0: total_batches may be 0) has a tail
+    // of waves running out of paths.  Which launch finishes a path never affects its result.
+    uint32_t* carry;              // PT_CARRY_STRIDE_DW dwords per wave of the grid
+    uint32_t carry_in_waves;
+    uint32_t carry_out;
+    // how batches are dealt to waves (pt_queue_refill): numbered over the whole render, this launch's chunk is [g_begin, g_static +
+    // total_batches); [g_begin, g_static) goes as static lists with stride n_waves (the grid, in waves), the rest comes off the queue
+    // on batch_counter; g_old_static: where the static lists of the PREVIOUS launch's chunk ended (lists a checkpoint left unfinished)
+    uint32_t n_waves, g_begin, g_static, g_old_static;
 };
+#define PT_QUEUE_STOP_WORD 32     // a work queue is two 128-byte lines: [0] the counter, [PT_QUEUE_STOP_WORD] the stop word of checkpointed launches
+#define PT_CARRY_RECORDS 64       // a wave stops with an empty pool and parks its (at most 64) live paths
+#define PT_CARRY_STRIDE_DW (16 + PT_CARRY_RECORDS * 15)   // header (paths, pix, end, ring frame, absolute frame) + the parked-path record as arrays
 
 struct PtFoldParams {
     const float* rad;   // [frame_count][npix_local][3]
     float4* fb;         // [npix_local] gamma-encoded running mean (GenerateColors.cl:314-321)
     uint32_t npix_local;
     int32_t frame_begin, frame_count;
+    unsigned int* reset_counter;  // the work-queue counter of the trace launch whose chunk this is: set back to zero for its next user
+    unsigned int* reset_counter2; // (may be null) a second one: the counter of the render's last, draining launch
 };
 
 // det_bound_bits: FOUR device words: [0] bit pattern of max_i (|e1|_1 * |e2|_1), [1] number of odd

@@ -984,7 +984,10 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         // pmc_r02_summary.txt: 35.2 bytes of HBM traffic per sample against 41.0 with aligned 16-byte records --
         // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
         // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
-        float* out = PT_ARG(rad) + ((size_t)s.fl * PT_ARG(npix_local) + s.lp) * 3u;
+        // (frame f of the render: entry (f + phase) % 2S of the staging ring, the first S entries in one slot, the others in the other)
+        const unsigned fr = s.fl + PT_ARG(ring_phase), S = PT_ARG(slot_frames);
+        const unsigned r = fr - __umulhi(fr, PT_ARG(ring_magic)) * (2u * S);
+        float* out = (r < S ? PT_ARG(rad) : PT_ARG(rad1)) + ((size_t)(r < S ? r : r - S) * PT_ARG(npix_local) + s.lp) * 3u;
         // (records are 12 bytes apart: the vector type is declared with the 4-byte alignment the address really has)
         typedef float pt_f3v __attribute__((ext_vector_type(3), aligned(4)));
         pt_f3v v;
@@ -1030,26 +1033,56 @@ PTK_DEV void pt_flush_counters(const PtTraceParams& P, unsigned lane, unsigned n
 #define PT_POOL 64  // parked-path slots per wave (a fresh phase parks at most 64 live paths)
 
 struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, end) of local pixels of `frame`
-    unsigned pix, end, frame;
+    unsigned pix, end, frame;   // frame: counted from the render's first frame (what a path keeps as `fl`)
     unsigned row, col;       // local row / column of `pix`, kept incrementally: no per-lane division
     unsigned sl, within;     // row = sl * stripe_rows + within (the stripe of the multi-GPU split)
-    bool exhausted;
+    unsigned g;              // the next batch of the wave's static list (pt_queue_refill), or:
 };
 
-// makes [q.pix, q.end) non-empty, taking the next batch off the global queue (one atomic per batch)
-// when the current one is used up; false when there is nothing left
+#define PT_Q_LIST_DONE 0xfffffffeu   // the list is done, the wave takes batches off the dynamic queue
+#define PT_Q_EMPTY 0xffffffffu       // ... and a grab has found that empty too
+
+// Makes [q.pix, q.end) non-empty when the current batch is used up; false when there is nothing (more) to start in this launch.
+// The batches (128 or 256 consecutive pixels of one frame) of the whole RENDER are numbered frame-major, g = frame x batches_per_frame
+// + i; a launch's chunk is [g_begin, g_limit).  They are dealt to the waves in two ways:
+//  * STATIC LISTS for the first part of a chunk, [g_begin, g_static) (checkpointed launches; n_waves != 0): wave w of the W in the grid
+//    owns g_begin + w, + W, + 2W, ...  No atomic, no round trip to the L2, nothing for 8 192 waves that start a launch together to
+//    queue up behind (measured: 0.17 ms per launch).  Within a frame the pixel batches are rotated by a frame-dependent amount, so a
+//    wave's batches wander over the image and the lists cost the same to a few per cent;
+//  * the DYNAMIC QUEUE for the rest, [g_static, g_limit): one atomic per batch on the launch's counter -- the waves that finish their
+//    lists early take more of it, so the launch's work runs out everywhere at about the same time.  Whoever takes its last batch
+//    raises the queue's STOP word (a cache line of its own behind the counter's: what the waves of a checkpointed launch poll,
+//    pt_queue_next, instead of the line the atomic adds go to).
+// A wave that was stopped inside its list goes on with it in the next launch (g < g_begin there: the previous chunk's, "old"), up
+// to that chunk's static limit g_old_static, and then starts this chunk's.  The LBVH kernel and PT_OPT_CHECKPOINT 0 have no lists
+// (g_static = g_begin): every batch comes off the queue, which a launch that runs every path out by itself needs.
 template <bool LATE>
 PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q)
 {
     const pt_kargs_p K = pt_kargs();
     if (q.pix != q.end) return true;
-    if (q.exhausted) return false;
-    unsigned b = 0;
-    if (lane == 0) b = atomicAdd(PT_ARG(batch_counter), 1u);
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= PT_ARG(total_batches)) { q.exhausted = true; return false; }
-    const unsigned f = b / PT_ARG(batches_per_frame);
-    const unsigned bi = b - f * PT_ARG(batches_per_frame);
+    unsigned g = q.g;
+    if (g < PT_Q_LIST_DONE) {
+        // a batch of the wave's list: this chunk's, or still the previous chunk's (g < g_begin), which ends at g_old_static -- then
+        // this chunk's begins, at the wave's own number; the value kept is always a batch still to do, or one of the two marks
+        unsigned nx = g + PT_ARG(n_waves);
+        if (g < PT_ARG(g_begin) && nx >= PT_ARG(g_old_static))
+            nx = PT_ARG(g_begin) + blockIdx.x * (PT_TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        q.g = nx < PT_ARG(g_static) ? nx : PT_Q_LIST_DONE;
+    } else {
+        if (g == PT_Q_EMPTY) return false;
+        unsigned b = 0;
+        if (lane == 0) b = atomicAdd(PT_ARG(batch_counter), 1u);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (PT_ARG(carry_out) != 0u && b + 1u >= PT_ARG(total_batches) && lane == 0u)
+            __hip_atomic_store(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b >= PT_ARG(total_batches)) { q.g = PT_Q_EMPTY; return false; }
+        q.g = PT_Q_LIST_DONE;
+        g = PT_ARG(g_static) + b;
+    }
+    const unsigned f = g / PT_ARG(batches_per_frame);
+    unsigned bi = g - f * PT_ARG(batches_per_frame) + (f * 40503u) % PT_ARG(batches_per_frame);   // (f < 32 768: no overflow)
+    if (bi >= PT_ARG(batches_per_frame)) bi -= PT_ARG(batches_per_frame);
     q.frame = f;
     q.pix = bi * PT_ARG(batch);
     const unsigned e = q.pix + PT_ARG(batch);
@@ -1077,7 +1110,7 @@ PTK_DEV void pt_pool_push(float4* pool, unsigned& pool_n, const PtPath& s, bool&
         unsigned* w = reinterpret_cast<unsigned*>(pool + 3 * PT_POOL) + 3u * k;
         w[0] = s.seed;
         w[1] = s.lp;
-        w[2] = s.fl | ((unsigned)s.bounce << 16);  // both below 65 536 (pt_render_frames checks)
+        w[2] = s.fl | ((unsigned)s.bounce << 16);  // both below 65 536 (pt_render_frames checks: the ring has fewer frames)
     }
     pool_n += (unsigned)__popcll(live);
     alive = false;
@@ -1117,6 +1150,98 @@ PTK_DEV void pt_pool_pop(float4* pool, unsigned& pool_n, PtPath& s, bool& alive)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- checkpointed launches (PtTraceParams::carry) ---------------------------------------------------------------------
+// A wave stops only where its pool is empty and a fresh phase would begin: it parks its live paths exactly as a fresh phase does
+// (the bounce loop's own pt_pool_push site -- a second copy of that code after the loop cost fourteen spilled registers INSIDE
+// the loop) and leaves; the pool then goes to the wave's region: 16 header dwords and the parked-path record as arrays of
+// PT_CARRY_RECORDS entries (three float4 arrays, three dword arrays: lane k moves entry k, coalesced).
+PTK_DEV void pt_carry_store(uint32_t* region, unsigned lane, const float4* pool, unsigned pool_n, const PtWaveQueue& q, unsigned n_rays, unsigned n_samples,
+                            unsigned n_carried)
+{
+    float4* A = reinterpret_cast<float4*>(region + 16);
+    unsigned* W = region + 16 + PT_CARRY_RECORDS * 12;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own pool writes, read by other lanes: as in pt_pool_pop
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < pool_n) {
+        A[lane] = pool[lane];
+        A[PT_CARRY_RECORDS + lane] = pool[PT_POOL + lane];
+        A[2 * PT_CARRY_RECORDS + lane] = pool[2 * PT_POOL + lane];
+        const unsigned* w = reinterpret_cast<const unsigned*>(pool + 3 * PT_POOL) + 3u * lane;
+        W[lane] = w[0];
+        W[PT_CARRY_RECORDS + lane] = w[1];
+        W[2 * PT_CARRY_RECORDS + lane] = w[2];
+    }
+    if (lane == 0u) {
+        region[0] = pool_n;
+        region[1] = q.pix;
+        region[2] = q.end;
+        region[3] = q.frame;
+        region[7] = q.g;
+        // the wave's tallies travel with the checkpoint and reach the stats buffer at the end of the render's last launch, where the
+        // waves leave one by one: 8 192 waves leaving TOGETHER, two or three atomics each on the same line, measured 0.25 ms per launch
+        region[4] = n_rays;
+        region[5] = n_samples;
+        region[6] = n_carried + pool_n + (q.end - q.pix);
+    }
+}
+
+// resumes a checkpoint: the parked paths go straight into lanes (at most 64: the pool was empty when they were parked), the rest
+// of the batch becomes the wave's current range
+template <bool LATE>
+PTK_DEV void pt_carry_load(const PtTraceParams& P, const uint32_t* region, unsigned lane, PtPath& s, bool& alive, PtWaveQueue& q, unsigned& n_rays,
+                           unsigned& n_samples, unsigned& n_carried)
+{
+    const pt_kargs_p K = pt_kargs();
+    const unsigned n = __builtin_amdgcn_readfirstlane(region[0]);
+    n_rays = __builtin_amdgcn_readfirstlane(region[4]);
+    n_samples = __builtin_amdgcn_readfirstlane(region[5]);
+    n_carried = __builtin_amdgcn_readfirstlane(region[6]);
+    q.pix = __builtin_amdgcn_readfirstlane(region[1]);
+    q.end = __builtin_amdgcn_readfirstlane(region[2]);
+    q.frame = __builtin_amdgcn_readfirstlane(region[3]);
+    q.g = __builtin_amdgcn_readfirstlane(region[7]);
+    q.row = q.pix / (unsigned)PT_ARG(width);
+    q.col = q.pix - q.row * (unsigned)PT_ARG(width);
+    q.sl = q.row / (unsigned)PT_ARG(stripe_rows);
+    q.within = q.row - q.sl * (unsigned)PT_ARG(stripe_rows);
+    const float4* A = reinterpret_cast<const float4*>(region + 16);
+    const unsigned* W = region + 16 + PT_CARRY_RECORDS * 12;
+    if (lane < n) {
+        const float4 a0 = A[lane], a1 = A[PT_CARRY_RECORDS + lane], a2 = A[2 * PT_CARRY_RECORDS + lane];
+        const unsigned w2 = W[2 * PT_CARRY_RECORDS + lane];
+        s.o = mk3(a0.x, a0.y, a0.z);
+        s.d = mk3(a0.w, a1.x, a1.y);
+        s.mask = mk3(a1.z, a1.w, a2.x);
+        s.L = mk3(a2.y, a2.z, a2.w);
+        s.seed = W[lane];
+        s.lp = W[PT_CARRY_RECORDS + lane];
+        s.fl = w2 & 0xffffu;
+        s.bounce = (int)(w2 >> 16);
+        alive = true;
+    }
+}
+
+// The wave is at a fresh-phase boundary (its pool is empty, some lane is dead).  1: [q.pix, q.end) holds samples to start;
+// 0: nothing left to start (the classic end: the wave runs its last paths out); 2: STOP -- this launch ends with a
+// checkpoint (carry_out): the launch's queue has handed out its last batch (its stop word is up: one line of its own, written
+// once, polled by one lane per wave and fresh phase), and this wave holds nothing of the PREVIOUS launch's chunk any more,
+// whose fold follows this launch.
+template <bool LATE>
+PTK_DEV int pt_queue_next(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, const PtPath& s, bool alive)
+{
+    const pt_kargs_p K = pt_kargs();
+    if (PT_ARG(carry_out) != 0u) {
+        unsigned stop = 0u;
+        if (lane == 0u) stop = __hip_atomic_load(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stop = (unsigned)__builtin_amdgcn_readfirstlane(stop);
+        // (of the previous chunk: a batch under way, batches of the list not yet begun, paths in lanes -- the pool is empty)
+        if (stop != 0u && !(q.pix != q.end && q.frame < PT_ARG(chunk_f0)) && q.g >= PT_ARG(g_begin) && __ballot(alive && s.fl < PT_ARG(chunk_f0)) == 0ull)
+            return 2;
+    }
+    return pt_queue_refill<LATE>(P, lane, q) ? 1 : 0;
+}
+
 // FRESH phase: every lane is dead (its path parked); the next (up to) 64 samples of the wave's range start
 // in lanes 0.. at bounce 0 -- seed :308, camera ray :310
 // returns true when all 64 lanes started a primary ray
@@ -1140,7 +1265,7 @@ PTK_DEV bool pt_start_fresh(const PtTraceParams& P, unsigned lane, PtWaveQueue& 
             grow = (sl * (unsigned)PT_ARG(n_ranks) + (unsigned)PT_ARG(rank)) * SR + within;
         }
         const unsigned gid = grow * W + x;
-        const int frame = PT_ARG(frame_begin) + (int)q.frame;
+        const int frame = PT_ARG(frame_begin) - (int)PT_ARG(chunk_f0) + (int)q.frame;   // (the render's first frame + q.frame)
         s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
         pt_generate_ray((int)x, (int)grow, PT_ARG(inv_width), PT_ARG(inv_height), PT_ARG(aspect), s.seed, s.o, s.d);      // :310
         s.mask = mk3(1.0f, 1.0f, 1.0f);
@@ -1175,7 +1300,8 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         __syncthreads();
     }
     // this wave's pool of parked paths, behind the triangle table (ptk_trace_lds_bytes)
-    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + (threadIdx.x >> 6) * PT_POOL_DWORDS);
+    const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform to the compiler too: the addresses below live in SGPRs)
+    float4* pool = reinterpret_cast<float4*>(pt_lds_tab + (LDS_TABLE == 1 ? ntri * PT_LDS_TRI_STRIDE : 0) + wave_in_wg * PT_POOL_DWORDS);
     unsigned pool_n = 0u;                    // parked paths (wave-uniform)
     // this wave's pass-2 tail: 64 key slots + the pending-pair ring, behind the four pools
     PtTail tl;
@@ -1191,13 +1317,22 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         tl.keys[lane] = ~0ull;
     }
 
-    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, false };   // wave-uniform (SGPRs)
+    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };   // wave-uniform (SGPRs)
     bool alive = false;
     PtPath s;
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
     s.mask = mk3(1.0f, 1.0f, 1.0f); s.L = mk3(0.0f, 0.0f, 0.0f);
     s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
-    unsigned n_rays = 0, n_samples = 0;
+    unsigned n_rays = 0, n_samples = 0, n_carried = 0;   // (n_carried: samples this wave's checkpoints have handed on, PT_STAT_CARRIED)
+    // checkpointed launches: resume what the previous launch of the render left in this wave's region
+    // (the wave's number through readfirstlane: to the compiler threadIdx.x >> 6 differs between lanes, and so would everything below)
+    // the wave's list of this chunk begins at its own number (a checkpoint may say otherwise)
+    q.g = P.g_begin + blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg;
+    if (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg < P.carry_in_waves) {
+        pt_carry_load<true>(P, P.carry + (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) * PT_CARRY_STRIDE_DW, lane, s, alive, q, n_rays, n_samples, n_carried);
+        if (q.g >= PT_Q_LIST_DONE) q.g = P.g_begin + blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg;   // (it had finished the previous chunk's list)
+    }
+    if (q.g >= P.g_begin && q.g >= P.g_static) q.g = PT_Q_LIST_DONE;   // (no list for this wave in this chunk: every batch off the queue)
 #if PT_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0, c_p1 = 0;
 #endif
@@ -1210,9 +1345,13 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         PT_STAMP(t0);
         bool primary = false;   // (wave-uniform) this bounce is a fresh wave of 64 primary rays
         if (__ballot(!alive) != 0ull) {
-            if (pool_n == 0u && pt_queue_refill<true>(P, lane, q)) {
-                pt_pool_push(pool, pool_n, s, alive);                // park every live path ...
-                primary = pt_start_fresh<true>(P, lane, q, s, alive);      // ... and start 64 coherent primary rays
+            if (pool_n == 0u) {
+                const int next = pt_queue_next<true>(P, lane, q, s, alive);
+                if (next != 0) {
+                    pt_pool_push(pool, pool_n, s, alive);                // park every live path ...
+                    if (next == 2) break;                                // ... for the next launch (a checkpoint) ...
+                    primary = pt_start_fresh<true>(P, lane, q, s, alive);      // ... or start 64 coherent primary rays
+                }
             }
             pt_pool_pop(pool, pool_n, s, alive);           // dead lanes resume parked paths
         }
@@ -1274,6 +1413,15 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
 #endif
     }
 #endif
+    {
+        // (a wave that left the loop because nothing was alive holds nothing: no parked path, no rest of a batch -- an empty checkpoint)
+        const pt_kargs_p K = pt_kargs();
+        if (K->carry_out != 0u) {
+            pt_carry_store(K->carry + (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) * PT_CARRY_STRIDE_DW, lane, pool, pool_n, q, n_rays, n_samples, n_carried);
+            return;   // (the tallies went with it)
+        }
+    }
+    if (P.stats && lane == 0 && n_carried != 0u) atomicAdd(&P.stats[7], (unsigned long long)n_carried);
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
@@ -1365,7 +1513,7 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
                 grow = (sl * (unsigned)PT_ARG(n_ranks) + (unsigned)PT_ARG(rank)) * (unsigned)PT_ARG(stripe_rows) + within;
             }
             const unsigned gid = grow * (unsigned)PT_ARG(width) + x;
-            const int frame = PT_ARG(frame_begin) + (int)q.frame;
+            const int frame = PT_ARG(frame_begin) - (int)PT_ARG(chunk_f0) + (int)q.frame;
             s.seed = gid + pt_hash_u32((uint32_t)frame);                                 // :308
             pt_generate_ray((int)x, (int)grow, PT_ARG(inv_width), PT_ARG(inv_height), PT_ARG(aspect), s.seed, s.o, s.d);      // :310
             s.mask = mk3(1.0f, 1.0f, 1.0f);
@@ -1438,6 +1586,13 @@ typedef __attribute__((address_space(3))) unsigned char pt_lds_u8;
 // turns them into PT_ERR_TRAVERSAL (pt_render_frames); neither can happen with a hierarchy pt_bvh.hip built (see PT_BVH_STACK)
 #define PT_BVH_FLAG_STACK 1u   // a group had to be pushed beyond the stack's capacity
 #define PT_BVH_FLAG_BUDGET 2u  // more node visits than the hierarchy has nodes
+// The word lives in HOST memory mapped into the device's address space (pt_shim.hip: no render waits for the device to read
+// it): one word per bit, raised by a plain system-scope store -- no read-modify-write travels over PCIe, nothing is ever
+// read back by a kernel, and the path is taken by no ray of a valid hierarchy.
+PTK_DEV void pt_raise_flag(unsigned int* flags, unsigned bit)
+{
+    __hip_atomic_store(flags + (bit == PT_BVH_FLAG_STACK ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- the leaves: (leaf record, ray lane) pairs, tested 64 at a time --------------------------------------------------
 // With 64 incoherent lanes some lane meets a leaf at nearly every step, and each lane meets one only every ~10 nodes.  Round
@@ -1587,7 +1742,7 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
             if (L.sp < PT_BVH_LDS_STACK) { stk[(2 * L.sp) * PT_TRACE_THREADS] = L.gbase; stk[(2 * L.sp + 1) * PT_TRACE_THREADS] = L.gm; }
             else if (L.sp < (int)P.bvh_stack_limit) { ovf[2 * (L.sp - PT_BVH_LDS_STACK)] = L.gbase; ovf[2 * (L.sp - PT_BVH_LDS_STACK) + 1] = L.gm; }
             if (L.sp < (int)P.bvh_stack_limit) ++L.sp;
-            else atomicOr(P.bvh_flags, PT_BVH_FLAG_STACK);  // the group is lost: the host reports the render as failed
+            else pt_raise_flag(P.bvh_flags, PT_BVH_FLAG_STACK);  // the group is lost: the host reports the render as failed
             if (TALLY) c_maxsp = (unsigned)L.sp > c_maxsp ? (unsigned)L.sp : c_maxsp;
         }
         if (hn != 0u) {
@@ -1597,7 +1752,7 @@ PTK_DEV void pt_bvh_step(const PtTraceParams& P, PtBvhLane& L, bool& trav, const
         --L.budget;
         // a lane with nothing left to enter is done with the nodes (its last leaves may still be in the ring)
         if (((L.gm & 255u) == 0u) && L.sp == 0) trav = false;
-        if ((int)L.budget <= 0) { if (trav) atomicOr(P.bvh_flags, PT_BVH_FLAG_BUDGET); trav = false; }
+        if ((int)L.budget <= 0) { if (trav) pt_raise_flag(P.bvh_flags, PT_BVH_FLAG_BUDGET); trav = false; }
     }
     // ---- the leaf children just hit join the wave's pending pairs ----------------------------
     for (pt_lanes has = PT_LANES(ht != 0u); has != 0ull; has = PT_LANES(ht != 0u)) {
@@ -1665,7 +1820,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     }
     pt_const_f32p bigT = (pt_const_f32p)(const float*)P.bigtab;
 
-    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, false };
+    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, PT_Q_LIST_DONE };   // (no static lists here: every batch comes off the queue)
     bool alive = false;  // the lane holds a path
     bool trav = false;   // ... whose closest-hit search is in progress
     PtPath s;
@@ -1866,6 +2021,10 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
     // one lane per (pixel, channel): the three channels are independent chains, and
     // a rank's share of a multi-GPU render has too few pixels to fill the chip with one lane per pixel
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0u) {   // (the trace launches that used them have completed: stream order)
+        if (P.reset_counter != nullptr) P.reset_counter[0] = P.reset_counter[PT_QUEUE_STOP_WORD] = 0u;
+        if (P.reset_counter2 != nullptr) P.reset_counter2[0] = P.reset_counter2[PT_QUEUE_STOP_WORD] = 0u;
+    }
     const unsigned lp = tid / 3u, ch = tid - 3u * lp;
     if (lp >= P.npix_local) return;
     float* fbp = reinterpret_cast<float*>(P.fb + lp) + ch;

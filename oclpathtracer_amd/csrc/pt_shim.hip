@@ -85,9 +85,10 @@ struct pt_device_s {
     int idx;
     hipDeviceProp_t prop;
     hipStream_t own_stream, stream;
+    bool external;           // `stream` is the caller's (pt_device_set_stream)
     uint64_t used, peak;
     int live_buffers;
-    int64_t opt_batch, opt_chunk, opt_profile, opt_quads, opt_accel, opt_tally, opt_pmask, opt_bvh_stack;
+    int64_t opt_batch, opt_chunk, opt_profile, opt_quads, opt_accel, opt_tally, opt_pmask, opt_bvh_stack, opt_lanes, opt_carry;
     pt_kernel_s kernels[KERNEL_COUNT];
     // prepared-scene cache
     PtPrepTriangle* prep;
@@ -114,12 +115,41 @@ struct pt_device_s {
     float* p1tab;               // quad mode 3: packed pass-1 table (pt_quad3_pass1), sized with prep
     float prep_p1_lo, prep_p1_hi;
     unsigned int* det_bound_dev;  // PT_PREP_WORDS device words written by the prep kernel
-    // fused-render workspace
-    float* rad;              // radiance staging: 12 bytes per (frame, pixel) of a chunk
-    size_t rad_bytes;
+    // fused-render workspace: the STREAMING renderer.  A render walks its frames in chunks of S frames (as many as a ring slot
+    // holds) through a ring of two radiance slots; chunk number seq (a running number over all renders of the handle) uses slot
+    // seq % 2.  All launches of ONE render go to one lane, in order:
+    //     T(0)  T(1) F(0)  T(2) F(1)  ...  T(n-1) F(n-2)  D  F(n-1)
+    // T(c) = trace launch of chunk c, CHECKPOINTED (PtTraceParams::carry): it ends the moment its queue has handed out the last
+    // batch, every wave saving the paths it still holds, and T(c+1) resumes them beside its own samples -- a launch has no tail
+    // of waves running out of paths, so chunks as short as a 192 MiB slot forces cost what one long launch costs.  F(c), the
+    // fold of chunk c into the framebuffer, therefore follows T(c+1), which finishes chunk c's last paths; D is a launch with an
+    // empty queue that finishes the last chunk's.  (The LBVH kernel keeps its traversal state in LDS and scratch and is not
+    // checkpointed: T(0) F(0) T(1) F(1) ..., every launch runs its paths out.)
+    // Consecutive renders ALTERNATE between the two lanes: render k+1's T(0) needs the slot that F(n-2) of render k released, not
+    // the one F(n-1) is still to read, so it fills the machine while D of render k runs dry.  The folds of all chunks of all renders
+    // form ONE chain (events): every pixel folds its frames in ascending order (GenerateColors.cl:314-321).
+    float* ring;             // PT_RING_SLOTS x ring_slot_bytes: 12 bytes per (frame, pixel) of a chunk
+    size_t ring_slot_bytes;
+    hipStream_t lane[2];
+    hipEvent_t ev_fork;      // recorded on `stream`: what the lanes must wait for before a render's first launches
+    hipEvent_t ev_fold[2];   // recorded on lane L behind its latest fold
+    hipEvent_t ev_slot[2];   // recorded behind the latest fold that read ring slot s: the slot may be written again
+    hipEvent_t ev_ext;       // pt_device_wait_stream
+    bool fold_recorded[2], slot_recorded[2];
+    int last_fold_lane;      // the lane of the newest fold (its event is behind every earlier launch of both lanes)
+    bool lanes_busy;         // lane work is enqueued that `stream` has not been ordered behind
+    bool main_dirty;         // work has been enqueued on `stream` that the lanes have not been ordered behind
+    uint64_t chunk_seq, render_seq;
+    uint32_t* carry[2];      // per lane: the checkpoint regions of its renders' trace launches (PT_CARRY_STRIDE_DW dwords per wave)
+    size_t carry_waves;      // waves each of them holds
     uint2* pmask;            // primary-ray candidate masks of the local pixels (pt_primary_mask_kernel)
     size_t pmask_pixels;
-    unsigned int* counters;  // PT_MAX_CHUNKS batch counters
+    struct { const void* src; uint64_t version; int32_t g[7]; bool valid; } pmask_key;  // what the masks in hand were made for
+    unsigned int* counters;  // PT_QUEUE_COUNTERS work-queue counters, PT_QUEUE_STRIDE words apart: zero between launches
+    bool counters_dirty;     // a failed call may have left one non-zero
+    unsigned int* trav_host; // the LBVH's sticky "search cut short" words: host memory the kernels store to (PT_ERR_TRAVERSAL)
+    unsigned int* trav_dev;  // ... as the device addresses it
+    uint64_t workspace;      // device bytes held by this handle for itself
     int blocks_per_cu;
     PendingFrames pending;
     // per-kernel timing (pt_profile_*)
@@ -128,7 +158,12 @@ struct pt_device_s {
     size_t prof_used[PT_PROF_KINDS];
 };
 
-static int prof_begin(pt_device_s* d, int kind, hipEvent_t* stop_out)
+#define PT_RING_SLOTS 2
+#define PT_DEFAULT_SLOT_BYTES ((size_t)192 << 20)   // sixteen 1024 x 1024 frames of 12-byte radiance
+#define PT_QUEUE_COUNTERS 64                        // (the last two are the lanes' draining launches')
+#define PT_QUEUE_STRIDE 64                          // words: two 128-byte lines per queue (counter, stop word: PT_QUEUE_STOP_WORD)
+
+static int prof_begin(pt_device_s* d, int kind, hipStream_t st, hipEvent_t* stop_out)
 {
     *stop_out = nullptr;
     if (!d->prof_on) return PT_OK;
@@ -140,23 +175,45 @@ static int prof_begin(pt_device_s* d, int kind, hipEvent_t* stop_out)
         v.push_back({ a, b });
     }
     auto& pr = v[d->prof_used[kind]++];
-    HIP_TRY(hipEventRecord(pr.first, d->stream));
+    HIP_TRY(hipEventRecord(pr.first, st));
     *stop_out = pr.second;
     return PT_OK;
 }
 
-static int prof_end(pt_device_s* d, hipEvent_t stop)
+static int prof_end(hipStream_t st, hipEvent_t stop)
 {
-    if (stop) HIP_TRY(hipEventRecord(stop, d->stream));
+    if (stop) HIP_TRY(hipEventRecord(stop, st));
     return PT_OK;
 }
 
-#define PT_MAX_CHUNKS 4096
 #ifndef PT_DEFAULT_PRIMARY_MASKS
 #define PT_DEFAULT_PRIMARY_MASKS 1  // PT_OPT_PRIMARY_MASKS of a new device handle (A/B builds set 0)
 #endif
 
 static int g_init_count = 0;
+
+// device memory the handle holds for itself (pt_device_workspace_memory)
+static hipError_t ws_malloc(pt_device_s* d, void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) d->workspace += bytes;
+    else { *p = nullptr; (void)hipGetLastError(); }
+    return e;
+}
+template <class T> static hipError_t ws_malloc(pt_device_s* d, T** p, size_t bytes) { return ws_malloc(d, reinterpret_cast<void**>(p), bytes); }
+
+static void ws_free(pt_device_s* d, void* p, size_t bytes)
+{
+    if (!p) return;
+    hipFree(p);
+    d->workspace -= bytes;
+}
+
+static const size_t WS_BIGTAB = PT_BVH_BIG_MAX * sizeof(PtPrepTriangle);
+static const size_t WS_BIGIDX = (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid) + sizeof(unsigned);  // indices, count, the LBVH's grid, records in use
+static const size_t WS_COUNTERS = (size_t)PT_QUEUE_COUNTERS * PT_QUEUE_STRIDE * sizeof(unsigned int);
+static const size_t WS_DETBOUND = PT_PREP_WORDS * sizeof(unsigned int);
+static size_t ws_big_p1tab() { return ptk_p1tab_floats(PT_BVH_BIG_MAX) * sizeof(float) + PT_BVH_BIG_MAX * sizeof(PtRawTriangle); }  // + the big triangles' raw records
 
 static int use_device(pt_device_s* d)
 {
@@ -188,6 +245,40 @@ extern "C" int pt_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// everything a device handle owns (also the unwinding path of a pt_device_create that failed half-way)
+static void destroy_device_objects(pt_device_s* d)
+{
+    ws_free(d, d->prep, d->prep_capacity * sizeof(PtPrepTriangle));
+    ws_free(d, d->p1tab, ptk_p1tab_floats((int)d->prep_capacity) * sizeof(float));
+    ws_free(d, d->bvh, ptk_bvh_record_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
+    ws_free(d, d->ring, PT_RING_SLOTS * d->ring_slot_bytes);
+    ws_free(d, d->pmask, d->pmask_pixels * sizeof(uint2));
+    ws_free(d, d->counters, WS_COUNTERS);
+    ws_free(d, d->bigtab, WS_BIGTAB);
+    ws_free(d, d->bigidx, WS_BIGIDX);
+    ws_free(d, d->big_p1tab, ws_big_p1tab());
+    ws_free(d, d->det_bound_dev, WS_DETBOUND);
+    if (d->trav_host) hipHostFree(d->trav_host);
+    if (d->prof_pairs) {
+        for (int k = 0; k < PT_PROF_KINDS; ++k)
+            for (auto& pr : d->prof_pairs[k]) {
+                hipEventDestroy(pr.first);
+                hipEventDestroy(pr.second);
+            }
+        delete[] d->prof_pairs;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (d->ev_fold[k]) hipEventDestroy(d->ev_fold[k]);
+        if (d->ev_slot[k]) hipEventDestroy(d->ev_slot[k]);
+        ws_free(d, d->carry[k], d->carry_waves * PT_CARRY_STRIDE_DW * sizeof(uint32_t));
+        if (d->lane[k]) hipStreamDestroy(d->lane[k]);
+    }
+    if (d->ev_fork) hipEventDestroy(d->ev_fork);
+    if (d->ev_ext) hipEventDestroy(d->ev_ext);
+    if (d->own_stream) hipStreamDestroy(d->own_stream);
+    delete d;
 }
 
 extern "C" int pt_device_create(int device_idx, pt_device_t* out)
@@ -224,54 +315,55 @@ extern "C" int pt_device_create(int device_idx, pt_device_t* out)
     d->opt_accel = 0;
     d->opt_pmask = PT_DEFAULT_PRIMARY_MASKS;
     d->opt_bvh_stack = 64;
+    d->opt_lanes = 2;
+    d->opt_carry = 1;
     d->kernels[KERNEL_GENERATE_COLORS] = { KERNEL_GENERATE_COLORS, "GenerateColors", "GenerateColors" };
     d->kernels[KERNEL_FILL] = { KERNEL_FILL, "PtShimTest", "FillKernel" };
     d->kernels[KERNEL_MATH] = { KERNEL_MATH, "PtShimTest", "MathKernel" };
     d->kernels[KERNEL_FOLD_CHECK] = { KERNEL_FOLD_CHECK, "PtShimTest", "FoldCheckKernel" };
-    if (hipMalloc(&d->bigtab, PT_BVH_BIG_MAX * sizeof(PtPrepTriangle)) != hipSuccess ||
-        hipMalloc(&d->bigidx, (PT_BVH_BIG_MAX + 1) * sizeof(int) + sizeof(PtBvhGrid) + sizeof(unsigned)) != hipSuccess ||  // indices, count, the LBVH's grid, records in use
-        hipMalloc(&d->counters, (PT_MAX_CHUNKS + 1) * sizeof(unsigned int)) != hipSuccess ||  // + the LBVH's sticky flag word
-        hipMalloc(&d->big_p1tab, ptk_p1tab_floats(PT_BVH_BIG_MAX) * sizeof(float) + PT_BVH_BIG_MAX * sizeof(PtRawTriangle)) != hipSuccess ||  // + the big triangles' raw records
-        hipMalloc(&d->det_bound_dev, PT_PREP_WORDS * sizeof(unsigned int)) != hipSuccess) {
-        hipStreamDestroy(d->own_stream);
-        delete d;
+    d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
+    bool ok = ws_malloc(d, &d->bigtab, WS_BIGTAB) == hipSuccess && ws_malloc(d, &d->bigidx, WS_BIGIDX) == hipSuccess &&
+              ws_malloc(d, &d->counters, WS_COUNTERS) == hipSuccess && ws_malloc(d, &d->big_p1tab, ws_big_p1tab()) == hipSuccess &&
+              ws_malloc(d, &d->det_bound_dev, WS_DETBOUND) == hipSuccess;
+    // the render lanes and their events (no timing: they only order streams)
+    for (int k = 0; ok && k < 2; ++k)
+        ok = hipStreamCreateWithFlags(&d->lane[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&d->ev_fold[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&d->ev_slot[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&d->ev_ext, hipEventDisableTiming) == hipSuccess;
+    // the sticky words of PT_ERR_TRAVERSAL: host memory the LBVH kernels store to, read here without waiting for anything
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&d->trav_host), 64, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer(reinterpret_cast<void**>(&d->trav_dev), d->trav_host, 0) == hipSuccess;
+    if (ok) {
+        d->trav_host[0] = d->trav_host[1] = 0u;
+        ok = hipMemsetAsync(d->counters, 0, WS_COUNTERS, d->own_stream) == hipSuccess && hipStreamSynchronize(d->own_stream) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        destroy_device_objects(d);
         return fail(PT_ERR_OOM, "workspace allocation failed");
     }
     d->blocks_per_cu = ptk_trace_blocks_per_cu(36);
     d->bvh_blocks_per_cu = ptk_trace_bvh_blocks_per_cu();
-    d->prof_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>[PT_PROF_KINDS];
     *out = d;
     return PT_OK;
 }
 
 static int flush_pending(pt_device_s* d);
 
+static int lanes_join(pt_device_s* d);
+
 extern "C" int pt_device_destroy(pt_device_t d)
 {
     int rc = use_device(d);
     if (rc) return rc;
     rc = flush_pending(d);
+    lanes_join(d);
     hipStreamSynchronize(d->stream);
     if (d->live_buffers != 0)
         return fail(PT_ERR_INVALID, "%d buffer(s) of this device are still alive", d->live_buffers);
-    if (d->prep) hipFree(d->prep);
-    if (d->p1tab) hipFree(d->p1tab);
-    if (d->bvh) hipFree(d->bvh);
-    if (d->rad) hipFree(d->rad);
-    if (d->pmask) hipFree(d->pmask);
-    if (d->counters) hipFree(d->counters);
-    if (d->bigtab) hipFree(d->bigtab);
-    if (d->bigidx) hipFree(d->bigidx);
-    if (d->big_p1tab) hipFree(d->big_p1tab);
-    if (d->det_bound_dev) hipFree(d->det_bound_dev);
-    for (int k = 0; k < PT_PROF_KINDS; ++k)
-        for (auto& pr : d->prof_pairs[k]) {
-            hipEventDestroy(pr.first);
-            hipEventDestroy(pr.second);
-        }
-    delete[] d->prof_pairs;
-    hipStreamDestroy(d->own_stream);
-    delete d;
+    destroy_device_objects(d);
     return rc;
 }
 
@@ -302,22 +394,86 @@ extern "C" uint64_t pt_device_max_alloc(pt_device_t d) { return d ? (uint64_t)d-
 extern "C" uint64_t pt_device_mem_size(pt_device_t d) { return d ? (uint64_t)d->prop.totalGlobalMem : 0; }
 extern "C" uint64_t pt_device_used_memory(pt_device_t d) { return d ? d->used : 0; }
 extern "C" uint64_t pt_device_peak_memory(pt_device_t d) { return d ? d->peak : 0; }
+extern "C" uint64_t pt_device_workspace_memory(pt_device_t d) { return d ? d->workspace : 0; }
 extern "C" int pt_device_num_cus(pt_device_t d) { return d ? d->prop.multiProcessorCount : 0; }
+
+// ---- stream discipline -------------------------------------------------------------------------------------------------
+// The handle's stream carries every call but the fused renders, whose launches live on the two lanes (pt_device_s).  Two
+// one-way hand-overs keep the whole in call order:
+//   fork  (render_internal): the lanes wait for what is on `stream` -- only when something has been put there since the
+//         last fork (main_dirty), or the stream is the caller's, who may have enqueued on it without telling us;
+//   join  (lanes_join): `stream` waits for the newest fold -- only when a call needs the renders' results on `stream`, so
+//         that back-to-back renders never meet a join and overlap on the device.
+// a caller's stream handle: PT_STREAM_LEGACY (the value of HIP's hipStreamLegacy sentinel) is the legacy default stream, which every
+// HIP entry point knows as the null stream (the sentinel itself is not accepted by every runtime version torch ships)
+static hipStream_t as_stream(void* h) { return h == PT_STREAM_LEGACY ? nullptr : (hipStream_t)h; }
+
+static int lanes_join(pt_device_s* d)
+{
+    if (!d->lanes_busy) return PT_OK;
+    if (d->fold_recorded[d->last_fold_lane]) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_fold[d->last_fold_lane], 0));
+    d->lanes_busy = false;
+    return PT_OK;
+}
+
+// every entry point that enqueues on, or waits for, the handle's stream: deferred frames are submitted and the stream is
+// ordered behind the lanes first
+static int enter_stream(pt_device_s* d)
+{
+    int rc = flush_pending(d);
+    if (!rc) rc = lanes_join(d);
+    d->main_dirty = true;
+    return rc;
+}
+
+// PT_ERR_TRAVERSAL, deferred (include/pt_shim.h): read -- and clear -- the words the LBVH kernels raise.  Called wherever the
+// host observes the device; never waits for anything itself.
+static int check_traversal(pt_device_s* d)
+{
+    if (!d->trav_host) return PT_OK;
+    const unsigned st = __atomic_exchange_n(&d->trav_host[0], 0u, __ATOMIC_ACQ_REL);
+    const unsigned bu = __atomic_exchange_n(&d->trav_host[1], 0u, __ATOMIC_ACQ_REL);
+    if (!st && !bu) return PT_OK;
+    return fail(PT_ERR_TRAVERSAL, "LBVH search cut short (%s%s%s): the framebuffers of the renders since the last check are not valid",
+                st ? "stack capacity" : "", st && bu ? ", " : "", bu ? "step budget" : "");
+}
 
 extern "C" int pt_device_set_stream(pt_device_t d, void* hip_stream)
 {
     int rc = use_device(d);
     if (rc) return rc;
-    rc = flush_pending(d);
-    if (rc) return rc;
+    if ((rc = enter_stream(d))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));  // keep the one-queue ordering across the switch
     // NULL restores the handle's own (non-blocking) stream.  The legacy default stream -- what a
-    // caller's "stream 0" means -- is named by HIP's own sentinel hipStreamLegacy = PT_STREAM_LEGACY.
-    d->stream = hip_stream ? (hipStream_t)hip_stream : d->own_stream;
+    // caller's "stream 0" means -- is named by PT_STREAM_LEGACY and used as HIP's null stream.
+    d->stream = hip_stream ? as_stream(hip_stream) : d->own_stream;
+    d->external = hip_stream != nullptr;
     return PT_OK;
 }
 
-extern "C" void* pt_device_get_stream(pt_device_t d) { return d ? (void*)d->stream : nullptr; }
+extern "C" void* pt_device_get_stream(pt_device_t d) { return !d ? nullptr : d->external && !d->stream ? PT_STREAM_LEGACY : (void*)d->stream; }
+
+extern "C" int pt_device_wait_stream(pt_device_t d, void* hip_stream)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!hip_stream) return fail(PT_ERR_INVALID, "hip_stream == NULL (the legacy default stream is PT_STREAM_LEGACY)");
+    // (an event may be recorded again while a wait on its earlier record is pending: the wait keeps the record it saw)
+    HIP_TRY(hipEventRecord(d->ev_ext, as_stream(hip_stream)));
+    HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_ext, 0));
+    d->main_dirty = true;
+    return PT_OK;
+}
+
+extern "C" int pt_device_wait_hip_event(pt_device_t d, void* hip_event)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (!hip_event) return fail(PT_ERR_INVALID, "hip_event == NULL");
+    HIP_TRY(hipStreamWaitEvent(d->stream, (hipEvent_t)hip_event, 0));
+    d->main_dirty = true;
+    return PT_OK;
+}
 
 extern "C" int pt_sync(pt_device_t d)
 {
@@ -330,8 +486,9 @@ extern "C" int pt_sync(pt_device_t d)
     if (d->pending.active && (d->pending.tris->exposed || d->pending.mats->exposed || d->pending.fb->exposed) &&
         (rc = flush_pending(d)))
         return rc;
+    if ((rc = lanes_join(d))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
-    return PT_OK;
+    return check_traversal(d);
 }
 
 extern "C" int pt_flush(pt_device_t d)
@@ -339,6 +496,38 @@ extern "C" int pt_flush(pt_device_t d)
     int rc = use_device(d);
     if (rc) return rc;
     return flush_pending(d);
+}
+
+static int free_ring(pt_device_s* d)
+{
+    int rc = lanes_join(d);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));   // nothing in flight may still write it
+    ws_free(d, d->ring, PT_RING_SLOTS * d->ring_slot_bytes);
+    d->ring = nullptr;
+    d->ring_slot_bytes = 0;
+    return PT_OK;
+}
+
+static int alloc_ring(pt_device_s* d, size_t slot_bytes)
+{
+    slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+    hipError_t e = ws_malloc(d, &d->ring, PT_RING_SLOTS * slot_bytes);
+    if (e != hipSuccess) return fail(PT_ERR_OOM, "radiance staging ring (%d x %zu bytes) allocation failed: %s", PT_RING_SLOTS, slot_bytes, hipGetErrorString(e));
+    d->ring_slot_bytes = slot_bytes;
+    return PT_OK;
+}
+
+extern "C" int pt_device_reserve_staging(pt_device_t d, size_t bytes)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    const size_t slot = bytes ? (bytes + PT_RING_SLOTS - 1) / PT_RING_SLOTS : PT_DEFAULT_SLOT_BYTES;
+    if (slot < 12) return fail(PT_ERR_INVALID, "a staging slot holds at least one 12-byte sample");
+    if ((rc = flush_pending(d))) return rc;
+    if (d->ring && ((slot + 255) & ~(size_t)255) == d->ring_slot_bytes) return PT_OK;
+    if (d->ring && (rc = free_ring(d))) return rc;
+    return alloc_ring(d, slot);
 }
 
 extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
@@ -375,6 +564,17 @@ extern "C" int pt_device_set_option(pt_device_t d, int option, int64_t value)
         if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "the LBVH stack limit must be 1..64");
         d->opt_bvh_stack = value;
         return PT_OK;
+    case PT_OPT_RENDER_LANES:
+        if (value < 1 || value > 2) return fail(PT_ERR_INVALID, "render lanes must be 1 or 2");
+        rc = enter_stream(d);   // the next render forks: both lanes start behind everything enqueued under the old setting
+        d->opt_lanes = value;
+        return rc;
+    case PT_OPT_CHECKPOINT:
+        d->opt_carry = value ? 1 : 0;
+        return PT_OK;
+    case PT_OPT_RESERVED_3:   // ABI version 1's kernel-variant switch: both of its values select the one variant left
+        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "option 3 took 0 or 1");
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -391,6 +591,9 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_BVH_TALLY: return d->opt_tally;
     case PT_OPT_PRIMARY_MASKS: return d->opt_pmask;
     case PT_OPT_BVH_STACK_LIMIT: return d->opt_bvh_stack;
+    case PT_OPT_RENDER_LANES: return d->opt_lanes;
+    case PT_OPT_CHECKPOINT: return d->opt_carry;
+    case PT_OPT_RESERVED_3: return 0;
     default: return -1;
     }
 }
@@ -452,6 +655,7 @@ extern "C" int pt_buffer_free(pt_buffer_t b)
     int rc = use_device(d);
     if (rc) return rc;
     if (d->pending.active && (d->pending.tris == b || d->pending.mats == b || d->pending.fb == b)) rc = flush_pending(d);
+    lanes_join(d);
     hipStreamSynchronize(d->stream);  // nothing in flight may still touch it
     if (d->prep_src == b) d->prep_src = nullptr;
     if (b->staging) hipHostFree(b->staging);
@@ -511,7 +715,7 @@ extern "C" int pt_buffer_write(pt_buffer_t dst, const void* host_src, size_t byt
     int rc = check_range(dst, dst_offset, bytes, "pt_buffer_write");
     if (rc) return rc;
     pt_device_s* d = dst->dev;
-    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if ((rc = use_device(d)) || (rc = enter_stream(d))) return rc;
     if (!host_src && bytes) return fail(PT_ERR_INVALID, "null host pointer");
     if ((rc = event_begin(d, ev))) return rc;
     if (bytes) HIP_TRY(hipMemcpyAsync((char*)dst->dptr + dst_offset, host_src, bytes, hipMemcpyHostToDevice, d->stream));
@@ -524,7 +728,7 @@ extern "C" int pt_buffer_read(pt_buffer_t src, void* host_dst, size_t bytes, siz
     int rc = check_range(src, src_offset, bytes, "pt_buffer_read");
     if (rc) return rc;
     pt_device_s* d = src->dev;
-    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if ((rc = use_device(d)) || (rc = enter_stream(d))) return rc;
     if (!host_dst && bytes) return fail(PT_ERR_INVALID, "null host pointer");
     if ((rc = event_begin(d, ev))) return rc;
     if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, (const char*)src->dptr + src_offset, bytes, hipMemcpyDeviceToHost, d->stream));
@@ -539,7 +743,7 @@ extern "C" int pt_buffer_copy(pt_buffer_t dst, pt_buffer_t src, size_t bytes, si
     if ((rc = check_range(src, src_offset, bytes, "pt_buffer_copy(src)"))) return rc;
     if (dst->dev != src->dev) return fail(PT_ERR_INVALID, "buffers belong to different devices");
     pt_device_s* d = dst->dev;
-    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if ((rc = use_device(d)) || (rc = enter_stream(d))) return rc;
     if ((rc = event_begin(d, ev))) return rc;
     if (bytes)
         HIP_TRY(hipMemcpyAsync((char*)dst->dptr + dst_offset, (const char*)src->dptr + src_offset, bytes,
@@ -569,7 +773,7 @@ extern "C" void* pt_buffer_map(pt_buffer_t b, size_t bytes, int blocking)
 {
     if (!b) { fail(PT_ERR_INVALID, "null buffer handle"); return nullptr; }
     pt_device_s* d = b->dev;
-    if (use_device(d) || flush_pending(d)) return nullptr;
+    if (use_device(d) || enter_stream(d)) return nullptr;
     if (bytes == (size_t)-1) bytes = b->bytes;
     if (check_range(b, 0, bytes, "pt_buffer_map")) return nullptr;
     if (b->mapped) { fail(PT_ERR_INVALID, "buffer is already mapped"); return nullptr; }
@@ -592,6 +796,7 @@ extern "C" void* pt_buffer_map(pt_buffer_t b, size_t bytes, int blocking)
     if (blocking) {
         hipError_t e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) { fail(PT_ERR_HIP, "map sync failed: %s", hipGetErrorString(e)); return nullptr; }
+        if (check_traversal(d)) return nullptr;   // (the contents would be those of a failed render)
     }
     b->mapped = true;
     b->mapped_bytes = bytes;
@@ -604,7 +809,7 @@ extern "C" int pt_buffer_unmap(pt_buffer_t b, void* host_ptr)
     if (!b->mapped || host_ptr != b->staging) return fail(PT_ERR_INVALID, "pointer was not returned by pt_buffer_map of this buffer");
     pt_device_s* d = b->dev;
     int rc;
-    if ((rc = use_device(d)) || (rc = flush_pending(d))) return rc;
+    if ((rc = use_device(d)) || (rc = enter_stream(d))) return rc;
     // exactly the range pt_buffer_map handed out: the staging allocation is kept at its largest size
     // ever, and whatever lies beyond this map's range is a stale snapshot
     size_t bytes = std::min(b->mapped_bytes, b->bytes);
@@ -651,6 +856,17 @@ extern "C" int pt_event_wait(pt_event_t e)
     int rc = use_device(e->dev);
     if (rc) return rc;
     HIP_TRY(hipEventSynchronize(e->stop));
+    return check_traversal(e->dev);
+}
+
+extern "C" int pt_event_wait_on(pt_event_t e, void* hip_stream)
+{
+    if (!e) return fail(PT_ERR_INVALID, "null event handle");
+    if (!hip_stream) return fail(PT_ERR_INVALID, "hip_stream == NULL (the legacy default stream is PT_STREAM_LEGACY)");
+    if (!e->recorded) return PT_OK;
+    int rc = use_device(e->dev);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(as_stream(hip_stream), e->stop, 0));
     return PT_OK;
 }
 
@@ -676,7 +892,7 @@ extern "C" int pt_event_elapsed_ns(pt_event_t e, uint64_t* ns_out)
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->start, e->stop));
     *ns_out = (uint64_t)((double)ms * 1.0e6);
-    return PT_OK;
+    return check_traversal(e->dev);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,26 +913,35 @@ extern "C" int pt_local_rows(int height, int stripe_rows, int n_ranks, int rank)
 
 static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 {
+    // wrapped (caller-owned) memory can change behind our back, and so can a buffer whose device pointer has been handed
+    // out (pt_buffer_device_ptr: writes through it bump no version): always re-prepare those
+    if (d->prep_capacity >= (size_t)ntri && d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned && !tris->exposed)
+        return PT_OK;
+    // the prepared scene is about to change under whatever the lanes still run: the handle's stream goes behind them
+    int rc = lanes_join(d);
+    if (rc) return rc;
+    d->main_dirty = true;
     if (d->prep_capacity < (size_t)ntri) {
         HIP_TRY(hipStreamSynchronize(d->stream));
-        if (d->prep) hipFree(d->prep);
-        if (d->p1tab) hipFree(d->p1tab);
-        if (d->bvh) hipFree(d->bvh);
+        ws_free(d, d->prep, d->prep_capacity * sizeof(PtPrepTriangle));
+        ws_free(d, d->p1tab, ptk_p1tab_floats((int)d->prep_capacity) * sizeof(float));
+        ws_free(d, d->bvh, ptk_bvh_record_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
         d->prep = nullptr;
         d->p1tab = nullptr;
         d->bvh = nullptr;
         d->bvh_valid = false;
         d->prep_capacity = 0;
-        size_t cap = std::max<size_t>((size_t)ntri, 64);
-        hipError_t e = hipMalloc(&d->prep, cap * sizeof(PtPrepTriangle));
-        if (e == hipSuccess) e = hipMalloc(&d->p1tab, ptk_p1tab_floats((int)cap) * sizeof(float));
-        if (e != hipSuccess) return fail(PT_ERR_OOM, "scene workspace allocation failed: %s", hipGetErrorString(e));
-        d->prep_capacity = cap;
         d->prep_src = nullptr;
+        size_t cap = std::max<size_t>((size_t)ntri, 64);
+        hipError_t e = ws_malloc(d, &d->prep, cap * sizeof(PtPrepTriangle));
+        if (e == hipSuccess) e = ws_malloc(d, &d->p1tab, ptk_p1tab_floats((int)cap) * sizeof(float));
+        if (e != hipSuccess) {
+            ws_free(d, d->prep, cap * sizeof(PtPrepTriangle));
+            d->prep = nullptr;
+            return fail(PT_ERR_OOM, "scene workspace allocation failed: %s", hipGetErrorString(e));
+        }
+        d->prep_capacity = cap;
     }
-    // wrapped (caller-owned) memory can change behind our back, and so can a buffer whose device pointer has been handed
-    // out (pt_buffer_device_ptr: writes through it bump no version): always re-prepare those
-    if (d->prep_src == tris && d->prep_version == tris->version && d->prep_ntri == ntri && tris->owned && !tris->exposed) return PT_OK;
     HIP_TRY(ptk_prep_triangles((const PtRawTriangle*)tris->dptr, d->prep, ntri, d->det_bound_dev, d->stream));
     unsigned int words[PT_PREP_WORDS] = { 0u, 1u, 0x7fc00000u, 1u };
     HIP_TRY(hipMemcpyAsync(words, d->det_bound_dev, sizeof words, hipMemcpyDeviceToHost, d->stream));
@@ -759,9 +984,12 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
 {
     if (d->bvh_valid) return PT_OK;
+    int rc = lanes_join(d);   // (a render through the old hierarchy may still be running)
+    if (rc) return rc;
+    d->main_dirty = true;
     if (!d->bvh) {
-        hipError_t e = hipMalloc(&d->bvh, ptk_bvh_record_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
-        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e)); }
+        hipError_t e = ws_malloc(d, &d->bvh, ptk_bvh_record_count((int)d->prep_capacity) * sizeof(PtBvh8Node));
+        if (e != hipSuccess) return fail(PT_ERR_OOM, "BVH allocation failed: %s", hipGetErrorString(e));
     }
     const size_t temp_bytes = ptk_bvh_temp_bytes(ntri);
     void* temp = nullptr;
@@ -816,6 +1044,257 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     return PT_OK;
 }
 
+// one render of at most 32 768 frames: its launches on one lane (pt_device_s).  ev_start / ev_stop: the caller's event, when
+// this part begins / ends the call
+static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_buffer_s* fb, const pt_render_params& rp, uint32_t npix,
+                       pt_buffer_s* stats, pt_event_s* ev_start, pt_event_s* ev_stop)
+{
+    int rc;
+    // PT_OPT_ACCEL: 0 = BVH for scenes of PT_BVH_AUTO_MIN triangles or more, 1 = brute force, 2 = BVH (needs >= 2 triangles)
+    const bool use_bvh = rp.num_triangles >= 2 &&
+                         (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
+    if (!use_bvh && rp.num_triangles >= (1 << 26))
+        return fail(PT_ERR_INVALID, "the brute-force search packs a triangle index in 26 bits: use PT_OPT_ACCEL 0 or 2 for %d triangles", rp.num_triangles);
+    if (use_bvh && rp.num_triangles >= (1 << 25))
+        return fail(PT_ERR_INVALID, "the LBVH search packs a record index (2 x triangles) in 26 bits: %d triangles are too many", rp.num_triangles);
+    if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
+    if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
+
+    // ---- the staging ring: whole frames per chunk, as many as a slot holds -------------------------------------------------
+    // Steady state allocates nothing: the ring exists from the first render on (pt_device_reserve_staging) and is replaced
+    // only when ONE frame of this image does not fit a slot.
+    const uint64_t frame_bytes = (uint64_t)npix * 12;
+    if (!d->ring || d->ring_slot_bytes < frame_bytes) {
+        if (d->ring && (rc = free_ring(d))) return rc;
+        if ((rc = alloc_ring(d, (size_t)std::max<uint64_t>(frame_bytes, PT_DEFAULT_SLOT_BYTES)))) return rc;
+    }
+    uint64_t slot_frames = std::min<uint64_t>(d->ring_slot_bytes / frame_bytes, 16383);   // (fl + ring_phase stays below 65 536: pt_kernels.h, ring_magic)
+    if (d->opt_chunk > 0) slot_frames = std::min<uint64_t>(slot_frames, (uint64_t)d->opt_chunk);
+    const int nchunks = (int)(((uint64_t)rp.frame_count + slot_frames - 1) / slot_frames);
+    const int chunk = (rp.frame_count + nchunks - 1) / nchunks;      // S: equal chunks -- 40 frames through a 16-frame slot go 14, 14, 12
+
+    // primary-ray candidate masks: quad scenes of up to 64 triangles on the brute-force path (PT_OPT_PRIMARY_MASKS).  They are a
+    // function of the image geometry and the prepared scene: made when either changes, on the handle's stream, behind the lanes
+    const int quads_sel = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
+    const bool use_pmask = d->opt_pmask && quads_sel == 3 && !use_bvh && rp.num_triangles <= 64 && d->prep_det_bounded;
+    bool make_pmask = false;
+    if (use_pmask) {
+        const int32_t g[7] = { rp.width, rp.height, rp.stripe_rows, rp.n_ranks, rp.rank, (int32_t)npix, rp.num_triangles };
+        make_pmask = !d->pmask_key.valid || d->pmask_key.src != (const void*)tris || d->pmask_key.version != tris->version ||
+                     memcmp(d->pmask_key.g, g, sizeof g) != 0 || !tris->owned || tris->exposed;
+        if (make_pmask) {
+            if ((rc = lanes_join(d))) return rc;   // (a render with the old masks may still be running)
+            d->main_dirty = true;
+            d->pmask_key.valid = false;
+            if (d->pmask_pixels < npix) {
+                HIP_TRY(hipStreamSynchronize(d->stream));
+                ws_free(d, d->pmask, d->pmask_pixels * sizeof(uint2));
+                d->pmask = nullptr;
+                d->pmask_pixels = 0;
+                hipError_t e = ws_malloc(d, &d->pmask, (size_t)npix * sizeof(uint2));
+                if (e != hipSuccess) return fail(PT_ERR_OOM, "primary-mask allocation (%zu bytes) failed: %s", (size_t)npix * sizeof(uint2), hipGetErrorString(e));
+                d->pmask_pixels = npix;
+            }
+            d->pmask_key.src = tris;
+            d->pmask_key.version = tris->version;
+            memcpy(d->pmask_key.g, g, sizeof g);
+        }
+    }
+    if (d->counters_dirty) {   // an earlier call failed between a trace launch and the fold that resets its counter
+        if ((rc = lanes_join(d))) return rc;
+        HIP_TRY(hipMemsetAsync(d->counters, 0, WS_COUNTERS, d->stream));
+        d->main_dirty = true;
+        d->counters_dirty = false;
+    }
+
+    // Samples per work-queue grab.  A wave that finds the queue empty idles until the last wave is
+    // done, on average for half a batch: large batches (fewer atomics) when every wave gets many of
+    // them, smaller ones when the launch is short (a rank's share of a multi-GPU render, small images).
+    const uint64_t resident_waves = (uint64_t)d->prop.multiProcessorCount * (uint64_t)(use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu) * (PT_TRACE_THREADS / 64);
+    const uint64_t chunk_samples = (uint64_t)npix * (uint64_t)chunk;
+    // (not below 128: at 64 the ONE queue counter takes 4 M atomics per launch of configs[2] and the
+    // L2 atomic unit saturates -- measured +30 % launch time)
+    uint32_t batch = PT_TRACE_BATCH;
+    while (batch > 128u && chunk_samples / batch < 64u * resident_waves) batch >>= 1;
+    const uint32_t bpf = (npix + batch - 1) / batch;
+    if ((uint64_t)bpf * (uint64_t)rp.frame_count > 0xffffffffull) return fail(PT_ERR_INVALID, "render too large: more than 2^32 batches");
+
+    PtTraceParams tp;
+    memset(&tp, 0, sizeof tp);
+    tp.tris = d->prep;
+    tp.mats = (const PtRawMaterial*)mats->dptr;
+    tp.stats = stats ? (unsigned long long*)stats->dptr : nullptr;
+    tp.width = rp.width;
+    tp.height = rp.height;
+    tp.inv_width = 1.0f / (float)rp.width;     // IEEE quotients: the translation unit is compiled without fast-math
+    tp.inv_height = 1.0f / (float)rp.height;
+    tp.aspect = (float)rp.width / (float)rp.height;
+    tp.max_bounces = rp.max_bounces;
+    tp.ntri = rp.num_triangles;
+    tp.nmat = rp.num_materials;
+    tp.stripe_rows = rp.stripe_rows;
+    tp.n_ranks = rp.n_ranks;
+    tp.rank = rp.rank;
+    tp.npix_local = npix;
+    tp.batches_per_frame = bpf;
+    tp.batch = batch;
+    tp.quad_delta1 = use_bvh ? d->big_delta1 : d->prep_delta1;
+    tp.ray_radius = use_bvh ? d->big_ray_radius : d->prep_ray_radius;
+    tp.p1tab = use_bvh ? d->big_p1tab : d->p1tab;
+    tp.p1_lo = use_bvh ? d->big_p1_lo : d->prep_p1_lo;
+    tp.p1_hi = use_bvh ? d->big_p1_hi : d->prep_p1_hi;
+    tp.bvh = d->bvh;
+    tp.bvh_records = (int32_t)d->bvh_records;
+    tp.grid = d->bvh_grid;
+    tp.bigtab = d->bigtab;
+    tp.bigidx = d->bigidx;
+    tp.nbig = use_bvh ? d->nbig : 0;
+    tp.pmask = use_pmask ? d->pmask : nullptr;
+    tp.bvh_flags = d->trav_dev;
+    tp.bvh_stack_limit = (int32_t)d->opt_bvh_stack;
+    tp.slot_frames = (uint32_t)chunk;
+    tp.ring_magic = (uint32_t)(0x100000000ull / (2u * (uint32_t)chunk)) + 1u;
+    tp.rad = d->ring;
+    tp.rad1 = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ring) + d->ring_slot_bytes);
+    if (make_pmask) {
+        HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel)
+        d->pmask_key.valid = true;
+    }
+    // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
+    const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? (use_bvh ? d->big_quads : d->prep_quads) : 0;
+
+    // persistent grid: fill the chip, but never more waves than a chunk has batches; ONE grid for all launches of the render (a
+    // checkpoint is resumed by the wave of the same number)
+    const int wg_waves = PT_TRACE_THREADS / 64;
+    int blocks = d->prop.multiProcessorCount * (use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu);
+    {
+        const uint64_t blocks_needed = ((uint64_t)bpf * (uint64_t)chunk + wg_waves - 1) / wg_waves;
+        if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
+    }
+    const int ln = d->opt_lanes == 2 ? (int)(d->render_seq++ & 1u) : 0;
+    hipStream_t st = d->lane[ln];
+    // checkpointed launches: the table kernels (the LBVH kernel's traversal state lives in LDS and scratch)
+    const bool carry = d->opt_carry && !use_bvh;
+    if (carry) {
+        const size_t waves = (size_t)d->prop.multiProcessorCount * 8 * wg_waves;   // (no kernel has more than 8 workgroups per CU resident)
+        if ((size_t)blocks * wg_waves > waves) return fail(PT_ERR_INVALID, "grid larger than the checkpoint regions");
+        for (int k = 0; k < 2; ++k)
+            if (!d->carry[k]) {   // once per device handle, at its first such render
+                hipError_t e = ws_malloc(d, &d->carry[k], waves * PT_CARRY_STRIDE_DW * sizeof(uint32_t));
+                if (e != hipSuccess) return fail(PT_ERR_OOM, "checkpoint buffer allocation failed: %s", hipGetErrorString(e));
+                d->carry_waves = waves;
+            }
+    }
+
+    // ---- fork: the lanes go behind the handle's stream (what uploaded the scene, cleared the framebuffer, made the masks ...)
+    if (d->main_dirty || d->external) {
+        HIP_TRY(hipEventRecord(d->ev_fork, d->stream));
+        HIP_TRY(hipStreamWaitEvent(d->lane[0], d->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(d->lane[1], d->ev_fork, 0));
+        d->main_dirty = false;
+    }
+    d->lanes_busy = true;
+    d->counters_dirty = true;   // until the last fold of this call is enqueued
+    if (ev_start) HIP_TRY(hipEventRecord(ev_start->start, st));
+    tp.ring_phase = (uint32_t)((d->chunk_seq & 1u) ? chunk : 0);   // the render's first chunk goes to slot chunk_seq % 2
+    tp.carry = carry ? d->carry[ln] : nullptr;
+    unsigned int* const drain_counter = d->counters + (size_t)(PT_QUEUE_COUNTERS - 1 - ln) * PT_QUEUE_STRIDE;
+    unsigned int* prev_counter = nullptr;
+    int prev_slot = 0, prev_f0 = 0, prev_nf = 0;
+    hipEvent_t pstop;
+    // fold of the chunk [f0, f0 + nf) staged in ring slot `slot`: behind the newest fold of the other lane (the chain), then
+    // the slot is free again
+    bool chained = false;   // this render's folds are behind the previous render's (on the other lane)
+    auto fold = [&](int slot, int f0, int nf, unsigned int* reset, unsigned int* reset2) -> int {
+        const bool last = f0 + nf >= rp.frame_count, last_two = f0 + nf + chunk >= rp.frame_count;
+        if (!chained && d->fold_recorded[ln ^ 1]) HIP_TRY(hipStreamWaitEvent(st, d->ev_fold[ln ^ 1], 0));
+        chained = true;
+        PtFoldParams fp;
+        fp.rad = slot ? tp.rad1 : tp.rad;
+        fp.fb = (float4*)fb->dptr;
+        fp.npix_local = npix;
+        fp.frame_begin = rp.frame_begin + f0;
+        fp.frame_count = nf;
+        fp.reset_counter = reset;
+        fp.reset_counter2 = reset2;
+        int r = prof_begin(d, PT_PROF_FOLD, st, &pstop);
+        if (r) return r;
+        HIP_TRY(ptk_fold(fp, st));
+        if ((r = prof_end(st, pstop))) return r;
+        // what other lanes wait for: the slot is free again (the next render's first two chunks), the fold chain's newest link (its
+        // first fold; lanes_join) -- only a render's last two folds can be either
+        if (last_two) {
+            HIP_TRY(hipEventRecord(d->ev_slot[slot], st));
+            d->slot_recorded[slot] = true;
+        }
+        if (last) {
+            HIP_TRY(hipEventRecord(d->ev_fold[ln], st));
+            d->fold_recorded[ln] = true;
+            d->last_fold_lane = ln;
+        }
+        return PT_OK;
+    };
+    uint32_t old_static = 0u;   // where the previous launch's static lists ended
+    auto trace = [&](int f0, int nf, unsigned int* counter, bool carry_in, bool carry_out) -> int {
+        tp.batch_counter = counter;
+        tp.frame_begin = rp.frame_begin + f0;
+        tp.frame_count = nf;
+        tp.chunk_f0 = (uint32_t)f0;
+        tp.carry_in_waves = carry_in ? (uint32_t)(blocks * wg_waves) : 0u;
+        tp.carry_out = carry_out ? 1u : 0u;
+        // batches are numbered over the whole render; a checkpointed launch deals the first 7/8 of its chunk as static lists (equally
+        // many per wave) and the rest through the queue, which balances the end of the launch (pt_queue_refill)
+        const uint32_t waves = (uint32_t)(blocks * wg_waves);
+        const uint64_t nb = (uint64_t)bpf * (uint64_t)nf;
+        // (static lists are an experiment that LOST, profiles/r04/static_lists.txt: 0 of 8 eighths of a chunk dealt statically 33.1 ms per
+        // configs[2] step, 4 of 8 37.5, 8 of 8 42.2 -- waves differ persistently in speed, a list cannot be taken over by another wave, and
+        // the laggards hold every launch's end back; PT_SHIM_STATIC_EIGHTHS re-runs it)
+        static const int eighths = getenv("PT_SHIM_STATIC_EIGHTHS") ? atoi(getenv("PT_SHIM_STATIC_EIGHTHS")) : 0;
+        const uint64_t nstatic = carry ? (nb * (uint64_t)eighths / 8) / waves * waves : 0;
+        tp.n_waves = waves;
+        tp.g_begin = (uint32_t)((uint64_t)bpf * (uint64_t)f0);
+        tp.g_static = tp.g_begin + (uint32_t)nstatic;
+        tp.g_old_static = old_static;
+        tp.total_batches = (uint32_t)(nb - nstatic);
+        old_static = tp.g_static;
+        int r = prof_begin(d, PT_PROF_TRACE, st, &pstop);
+        if (r) return r;
+        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, use_bvh, d->opt_tally != 0 && stats != nullptr, st));
+        return prof_end(st, pstop);
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const int f0 = c * chunk;
+        const int nf = std::min(chunk, rp.frame_count - f0);
+        const uint64_t seq = d->chunk_seq++;
+        const int slot = (int)(seq & 1u);
+        unsigned int* counter = d->counters + (size_t)(seq % (PT_QUEUE_COUNTERS - 2)) * PT_QUEUE_STRIDE;
+        // the slot must have been folded out (by the other lane, when this is one of a render's first two chunks)
+        if (c < 2 && d->slot_recorded[slot]) HIP_TRY(hipStreamWaitEvent(st, d->ev_slot[slot], 0));
+        if ((rc = trace(f0, nf, counter, carry && c > 0, carry))) return rc;
+        if (!carry) {
+            if ((rc = fold(slot, f0, nf, counter, nullptr))) return rc;
+        } else {
+            // chunk c - 1 is complete now: this launch finished the paths its own left unfinished
+            if (c > 0 && (rc = fold(prev_slot, prev_f0, prev_nf, prev_counter, nullptr))) return rc;
+            prev_slot = slot; prev_f0 = f0; prev_nf = nf; prev_counter = counter;
+        }
+    }
+    if (carry) {
+        // D: an empty queue, no checkpoint at its end -- the last chunk's paths run out here (beside the next render's first
+        // launch on the other lane) -- and the last fold
+        if ((rc = trace(rp.frame_count, 0, drain_counter, true, false))) return rc;
+        if ((rc = fold(prev_slot, prev_f0, prev_nf, prev_counter, drain_counter))) return rc;
+    }
+    d->counters_dirty = false;
+    if (ev_stop) {
+        HIP_TRY(hipEventRecord(ev_stop->stop, st));
+        ev_stop->recorded = true;
+    }
+    // a stream of the caller's (pt_device_set_stream) promises stream order to code we cannot see: it goes behind the render now
+    if (d->external && (rc = lanes_join(d))) return rc;
+    return PT_OK;
+}
+
 // pixel_count: 0 = all local pixels; otherwise the first pixel_count local pixels (n_ranks must be 1)
 static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_buffer_s* fb,
                            const pt_render_params& rp, uint32_t pixel_count, pt_buffer_s* stats, pt_event_s* ev)
@@ -849,155 +1328,25 @@ static int render_internal(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats,
         return fail(PT_ERR_RANGE, "framebuffer holds %zu bytes, %u pixels need %zu", fb->bytes, npix, (size_t)npix * sizeof(float4));
     if (stats && stats->bytes < PT_STAT_WORDS * sizeof(uint64_t)) return fail(PT_ERR_RANGE, "stats buffer too small");
 
-    int rc = event_begin(d, ev);
+    // a search that was cut short in an earlier render is reported before anything new is enqueued (PT_ERR_TRAVERSAL is deferred)
+    int rc = check_traversal(d);
     if (rc) return rc;
-    if (npix == 0 || rp.frame_count == 0) return event_end(d, ev);
-    if ((rc = ensure_prep(d, tris, rp.num_triangles))) return rc;
-    // PT_OPT_ACCEL: 0 = BVH for scenes of PT_BVH_AUTO_MIN triangles or more, 1 = brute force, 2 = BVH (needs >= 2 triangles)
-    const bool use_bvh = rp.num_triangles >= 2 &&
-                         (d->opt_accel == 2 || (d->opt_accel == 0 && rp.num_triangles >= PT_BVH_AUTO_MIN));
-    if (use_bvh && (rc = ensure_bvh(d, tris, rp.num_triangles))) return rc;
-    if (!use_bvh && rp.num_triangles >= (1 << 26))
-        return fail(PT_ERR_INVALID, "the brute-force search packs a triangle index in 26 bits: use PT_OPT_ACCEL 0 or 2 for %d triangles", rp.num_triangles);
-    if (use_bvh && rp.num_triangles >= (1 << 25))
-        return fail(PT_ERR_INVALID, "the LBVH search packs a record index (2 x triangles) in 26 bits: %d triangles are too many", rp.num_triangles);
-
-    // frames per chunk: radiance staging is 12 B x pixels x frames
-    // (the driver is asked for the free-memory figure only when the staging buffer in hand cannot
-    // take the whole call: a steady-state render loop makes no runtime query at all)
-    uint64_t budget = d->rad_bytes;
-    if ((uint64_t)rp.frame_count * npix * 12 > budget) {
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        budget = std::max<uint64_t>((uint64_t)(total_b / 16), (uint64_t)npix * 12);
-        budget = std::min<uint64_t>(budget, (uint64_t)free_b / 2 + d->rad_bytes);
-        budget = std::max<uint64_t>(budget, d->rad_bytes);
+    if (ev && ev->dev != d) return fail(PT_ERR_INVALID, "event belongs to another device");
+    if (npix == 0 || rp.frame_count == 0) {
+        if ((rc = lanes_join(d)) || (rc = event_begin(d, ev))) return rc;
+        return event_end(d, ev);
     }
-    int chunk = (int)std::min<uint64_t>((uint64_t)rp.frame_count, std::max<uint64_t>(1, budget / ((uint64_t)npix * 12)));
-    chunk = std::min(chunk, 65535);  // a parked path packs its frame-in-chunk in 16 bits
-    if (d->opt_chunk > 0) chunk = (int)std::min<int64_t>(chunk, d->opt_chunk);
-    int nchunks = (rp.frame_count + chunk - 1) / chunk;
-    if (nchunks > PT_MAX_CHUNKS) {
-        chunk = (rp.frame_count + PT_MAX_CHUNKS - 1) / PT_MAX_CHUNKS;
-        nchunks = (rp.frame_count + chunk - 1) / chunk;
-        if ((uint64_t)chunk * npix * 12 > budget) return fail(PT_ERR_OOM, "not enough device memory for radiance staging");
-    }
-    size_t need = (size_t)chunk * npix * 12;
-    if (d->rad_bytes < need) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        if (d->rad) hipFree(d->rad);
-        d->rad = nullptr;
-        d->rad_bytes = 0;
-        hipError_t e = hipMalloc(&d->rad, need);
-        if (e != hipSuccess) return fail(PT_ERR_OOM, "radiance staging allocation (%zu bytes) failed: %s", need, hipGetErrorString(e));
-        d->rad_bytes = need;
-    }
-    HIP_TRY(hipMemsetAsync(d->counters, 0, (size_t)nchunks * sizeof(unsigned int), d->stream));
-    unsigned int* const bvh_flags = d->counters + PT_MAX_CHUNKS;
-    if (use_bvh) HIP_TRY(hipMemsetAsync(bvh_flags, 0, sizeof(unsigned int), d->stream));
-    // primary-ray candidate masks: quad scenes of up to 64 triangles on the brute-force path (PT_OPT_PRIMARY_MASKS)
-    const int quads_sel = (d->opt_quads == 0 || d->opt_quads == 4) ? d->prep_quads : 0;
-    const bool use_pmask = d->opt_pmask && quads_sel == 3 && !use_bvh && rp.num_triangles <= 64 && d->prep_det_bounded;
-    if (use_pmask && d->pmask_pixels < npix) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        if (d->pmask) hipFree(d->pmask);
-        d->pmask = nullptr;
-        d->pmask_pixels = 0;
-        hipError_t e = hipMalloc(&d->pmask, (size_t)npix * sizeof(uint2));
-        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OOM, "primary-mask allocation (%zu bytes) failed: %s", (size_t)npix * sizeof(uint2), hipGetErrorString(e)); }
-        d->pmask_pixels = npix;
-    }
-
-    // Samples per work-queue grab.  A wave that finds the queue empty idles until the last wave is
-    // done, on average for half a batch: large batches (fewer atomics) when every wave gets many of
-    // them, smaller ones when the launch is short (a rank's share of a multi-GPU render, small images).
-    const uint64_t resident_waves = (uint64_t)d->prop.multiProcessorCount * (uint64_t)(use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu) * (PT_TRACE_THREADS / 64);
-    const uint64_t chunk_samples = (uint64_t)npix * (uint64_t)std::min(chunk, rp.frame_count);
-    // (not below 128: at 64 the ONE queue counter takes 4 M atomics per launch of configs[2] and the
-    // L2 atomic unit saturates -- measured +30 % launch time)
-    uint32_t batch = PT_TRACE_BATCH;
-    while (batch > 128u && chunk_samples / batch < 64u * resident_waves) batch >>= 1;
-    const uint32_t bpf = (npix + batch - 1) / batch;
-    for (int c = 0; c < nchunks; ++c) {
-        int f0 = c * chunk;
-        int nf = std::min(chunk, rp.frame_count - f0);
-        uint64_t total_batches = (uint64_t)bpf * nf;
-        if (total_batches > 0xffffffffull) return fail(PT_ERR_INVALID, "chunk too large");
-        PtTraceParams tp;
-        memset(&tp, 0, sizeof tp);
-        tp.tris = d->prep;
-        tp.mats = (const PtRawMaterial*)mats->dptr;
-        tp.rad = d->rad;
-        tp.batch_counter = d->counters + c;
-        tp.stats = stats ? (unsigned long long*)stats->dptr : nullptr;
-        tp.width = rp.width;
-        tp.height = rp.height;
-        tp.inv_width = 1.0f / (float)rp.width;     // IEEE quotients: the translation unit is compiled without fast-math
-        tp.inv_height = 1.0f / (float)rp.height;
-        tp.aspect = (float)rp.width / (float)rp.height;
-        tp.frame_begin = rp.frame_begin + f0;
-        tp.frame_count = nf;
-        tp.max_bounces = rp.max_bounces;
-        tp.ntri = rp.num_triangles;
-        tp.nmat = rp.num_materials;
-        tp.stripe_rows = rp.stripe_rows;
-        tp.n_ranks = rp.n_ranks;
-        tp.rank = rp.rank;
-        tp.npix_local = npix;
-        tp.batches_per_frame = bpf;
-        tp.total_batches = (uint32_t)total_batches;
-        tp.batch = batch;
-        tp.quad_delta1 = use_bvh ? d->big_delta1 : d->prep_delta1;
-        tp.ray_radius = use_bvh ? d->big_ray_radius : d->prep_ray_radius;
-        tp.p1tab = use_bvh ? d->big_p1tab : d->p1tab;
-        tp.p1_lo = use_bvh ? d->big_p1_lo : d->prep_p1_lo;
-        tp.p1_hi = use_bvh ? d->big_p1_hi : d->prep_p1_hi;
-        tp.bvh = d->bvh;
-        tp.bvh_records = (int32_t)d->bvh_records;
-        tp.grid = d->bvh_grid;
-        tp.bigtab = d->bigtab;
-        tp.bigidx = d->bigidx;
-        tp.nbig = use_bvh ? d->nbig : 0;
-        tp.pmask = use_pmask ? d->pmask : nullptr;
-        tp.bvh_flags = bvh_flags;
-        tp.bvh_stack_limit = (int32_t)d->opt_bvh_stack;
-        if (c == 0 && use_pmask) HIP_TRY(ptk_primary_masks(tp, d->stream));  // (cheap: one thread per pixel; geometry may differ per call)
-        // PT_OPT_QUAD_FILTER: 0 / 4 = the packed shared-u filter when the scene allows it, 1..3 = independent triangles
-        const int quads = (d->opt_quads == 0 || d->opt_quads == 4) ? (use_bvh ? d->big_quads : d->prep_quads) : 0;
-        // persistent grid: fill the chip, but never more waves than batches
-        const int wg_waves = PT_TRACE_THREADS / 64;
-        uint64_t waves_needed = total_batches;
-        int blocks = d->prop.multiProcessorCount * (use_bvh ? d->bvh_blocks_per_cu : d->blocks_per_cu);
-        uint64_t blocks_needed = (waves_needed + wg_waves - 1) / wg_waves;
-        if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
-        hipEvent_t pstop;
-        if ((rc = prof_begin(d, PT_PROF_TRACE, &pstop))) return rc;
-        HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, use_bvh, d->opt_tally != 0 && stats != nullptr, d->stream));
-        if ((rc = prof_end(d, pstop))) return rc;
-        PtFoldParams fp;
-        fp.rad = d->rad;
-        fp.fb = (float4*)fb->dptr;
-        fp.npix_local = npix;
-        fp.frame_begin = rp.frame_begin + f0;
-        fp.frame_count = nf;
-        if ((rc = prof_begin(d, PT_PROF_FOLD, &pstop))) return rc;
-        HIP_TRY(ptk_fold(fp, d->stream));
-        if ((rc = prof_end(d, pstop))) return rc;
+    // a path keeps its frame, counted from the render's first, in 16 bits: longer renders go in parts (each its own sequence
+    // of launches on one lane; the fold chain joins them)
+    const int PART = 32768;
+    pt_render_params part = rp;
+    for (int done = 0; done < rp.frame_count; done += PART) {
+        part.frame_begin = rp.frame_begin + done;
+        part.frame_count = std::min(PART, rp.frame_count - done);
+        if ((rc = render_part(d, tris, mats, fb, part, npix, stats, done == 0 ? ev : nullptr, done + PART >= rp.frame_count ? ev : nullptr))) return rc;
     }
     fb->version++;
     if (stats) stats->version++;
-    if ((rc = event_end(d, ev))) return rc;
-    if (use_bvh) {
-        // The reference's brute force cannot skip a triangle (GenerateColors.cl:137-154); a search through the hierarchy
-        // that was cut short could -- so that is never silent: the kernels raise a sticky flag and the render FAILS.
-        // (One host synchronisation per LBVH render; such a render runs for milliseconds to seconds.)
-        unsigned int flags = 0;
-        HIP_TRY(hipMemcpyAsync(&flags, bvh_flags, sizeof flags, hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        if (flags != 0)
-            return fail(PT_ERR_TRAVERSAL, "LBVH search cut short (%s%s%s): the framebuffer of this render is not valid",
-                        (flags & 1u) ? "stack capacity" : "", (flags & 3u) == 3u ? ", " : "", (flags & 2u) ? "step budget" : "");
-    }
     return PT_OK;
 }
 
@@ -1041,7 +1390,7 @@ extern "C" int pt_assemble_stripes_on(pt_device_t d, pt_buffer_t gathered, pt_bu
     if (!hip_stream) return fail(PT_ERR_INVALID, "hip_stream == NULL (pt_assemble_stripes uses the handle's own stream)");
     if ((rc = assemble_check(d, gathered, image, width, height, stripe_rows, n_ranks, slab_rows)) || (rc = flush_pending(d))) return rc;
     HIP_TRY(ptk_assemble_stripes((const float4*)gathered->dptr, (float4*)image->dptr, width, height, stripe_rows, n_ranks,
-                                 slab_rows, (hipStream_t)hip_stream));
+                                 slab_rows, as_stream(hip_stream)));
     image->version++;
     return PT_OK;
 }
@@ -1064,7 +1413,7 @@ extern "C" int pt_assemble_stripes(pt_device_t d, pt_buffer_t gathered, pt_buffe
     int rc = use_device(d);
     if (rc) return rc;
     if ((rc = assemble_check(d, gathered, image, width, height, stripe_rows, n_ranks, slab_rows))) return rc;
-    if ((rc = flush_pending(d)) || (rc = event_begin(d, ev))) return rc;
+    if ((rc = enter_stream(d)) || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_assemble_stripes((const float4*)gathered->dptr, (float4*)image->dptr, width, height, stripe_rows, n_ranks,
                                  slab_rows, d->stream));
     image->version++;
@@ -1079,7 +1428,7 @@ extern "C" int pt_tonemap_ppm(pt_device_t d, pt_buffer_t framebuffer, pt_buffer_
     if (framebuffer->dev != d || rgb_i32->dev != d) return fail(PT_ERR_INVALID, "buffer belongs to another device");
     if (num_pixels * sizeof(float4) > framebuffer->bytes) return fail(PT_ERR_RANGE, "framebuffer too small");
     if (num_pixels * 3 * sizeof(int32_t) > rgb_i32->bytes) return fail(PT_ERR_RANGE, "rgb buffer too small");
-    if ((rc = flush_pending(d)) || (rc = event_begin(d, ev))) return rc;
+    if ((rc = enter_stream(d)) || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_tonemap_ppm((const float4*)framebuffer->dptr, (int32_t*)rgb_i32->dptr, num_pixels, d->stream));
     rgb_i32->version++;
     return event_end(d, ev);
@@ -1097,6 +1446,7 @@ extern "C" int pt_profile_reset(pt_device_t d)
 {
     int rc = use_device(d);
     if (rc) return rc;
+    if ((rc = enter_stream(d))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
     for (int k = 0; k < PT_PROF_KINDS; ++k) d->prof_used[k] = 0;
     return PT_OK;
@@ -1107,7 +1457,7 @@ extern "C" int pt_profile_query(pt_device_t d, int kind, double* total_ms, uint6
     int rc = use_device(d);
     if (rc) return rc;
     if (kind < 0 || kind >= PT_PROF_KINDS || !total_ms || !launches) return fail(PT_ERR_INVALID, "bad profile query");
-    if ((rc = flush_pending(d))) return rc;
+    if ((rc = enter_stream(d))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
     double sum = 0.0;
     for (size_t i = 0; i < d->prof_used[kind]; ++i) {
@@ -1117,6 +1467,34 @@ extern "C" int pt_profile_query(pt_device_t d, int kind, double* total_ms, uint6
     }
     *total_ms = sum;
     *launches = d->prof_used[kind];
+    return check_traversal(d);
+}
+
+extern "C" int pt_profile_query_union(pt_device_t d, int kind, double* union_ms)
+{
+    int rc = use_device(d);
+    if (rc) return rc;
+    if (kind < 0 || kind >= PT_PROF_KINDS || !union_ms) return fail(PT_ERR_INVALID, "bad profile query");
+    if ((rc = enter_stream(d))) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    // launches are recorded in enqueue order and two lanes alternate: [start, stop] intervals relative to the first start,
+    // swept in order of their starts
+    const size_t n = d->prof_used[kind];
+    std::vector<std::pair<double, double>> iv(n);
+    for (size_t i = 0; i < n; ++i) {
+        float a = 0.f, b = 0.f;
+        if (i) HIP_TRY(hipEventElapsedTime(&a, d->prof_pairs[kind][0].first, d->prof_pairs[kind][i].first));
+        HIP_TRY(hipEventElapsedTime(&b, d->prof_pairs[kind][0].first, d->prof_pairs[kind][i].second));
+        iv[i] = { (double)a, (double)b };
+    }
+    std::sort(iv.begin(), iv.end());
+    double total = 0.0, end = -1.0e300;
+    for (auto& x : iv) {
+        if (x.second <= end) continue;
+        total += x.second - std::max(x.first, end);
+        end = x.second;
+    }
+    *union_ms = total;
     return PT_OK;
 }
 
@@ -1200,6 +1578,9 @@ static int launch_generate_colors(pt_device_s* d, const pt_launch_arg* a, int na
     rp.stripe_rows = 1; rp.n_ranks = 1; rp.rank = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (d->opt_profile) {
+        int jrc = lanes_join(d);   // earlier renders are not part of this launch's time
+        if (jrc) return jrc;
+        d->main_dirty = true;      // ... and the lanes start behind e0
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, d->stream));
@@ -1207,6 +1588,7 @@ static int launch_generate_colors(pt_device_s* d, const pt_launch_arg* a, int na
     int rc = render_internal(d, t, m, fb, rp, (uint32_t)npix, nullptr, ev);
     if (d->opt_profile) {
         float ms = 0.f;
+        if (!rc) rc = lanes_join(d);   // PROFILE_RETURN_TIME: the launch's duration as the handle's stream sees it
         if (!rc) {
             hipEventRecord(e1, d->stream);
             hipEventSynchronize(e1);
@@ -1231,7 +1613,7 @@ static int launch_fill(pt_device_s* d, const pt_launch_arg* a, int nargs, long l
     int32_t v;
     memcpy(&v, a[1].data, 4);
     long long cnt = std::min<long long>(n, (long long)(b->bytes / 4));
-    int rc = flush_pending(d);
+    int rc = enter_stream(d);
     if (rc || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_fill_i32((int32_t*)b->dptr, v, (int)std::min<long long>(cnt, 0x7fffffff), d->stream));
     b->version++;
@@ -1245,7 +1627,7 @@ static int launch_math(pt_device_s* d, const pt_launch_arg* a, int nargs, long l
     pt_buffer_s *in = a[0].buffer, *out = a[1].buffer;
     if (!in || !out || in->dev != d || out->dev != d) return fail(PT_ERR_ARGS, "MathKernel: bad buffer");
     long long cnt = std::min<long long>(n, std::min<long long>((long long)(in->bytes / 4), (long long)(out->bytes / 16)));
-    int rc = flush_pending(d);
+    int rc = enter_stream(d);
     if (rc || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_math((const float*)in->dptr, (float*)out->dptr, (int)std::min<long long>(cnt, 0x7fffffff), d->stream));
     out->version++;
@@ -1269,7 +1651,7 @@ static int launch_fold_check(pt_device_s* d, const pt_launch_arg* a, int nargs, 
     memcpy(&first, a[2].data, 4);
     memcpy(&count, a[3].data, 8);
     if (mode < 0 || mode > 4) return fail(PT_ERR_ARGS, "FoldCheckKernel: mode %d", mode);
-    int rc = flush_pending(d);
+    int rc = enter_stream(d);
     if (rc || (rc = event_begin(d, ev))) return rc;
     HIP_TRY(ptk_fold_check((unsigned long long*)out->dptr, mode, first, count, d->stream));
     out->version++;

@@ -83,24 +83,23 @@ class StripeImage:
 
     def __init__(self, dev: adl.Device, triangles, materials, width: int, height: int, *, world: int = 1, rank: int = 0,
                  stripe_rows: int = 16, want_stats: bool = False, pipelined: bool = False):
-        """``pipelined``: two local framebuffers and two gather buffers, so that the collective of one render can run
-        while the next render is already on the GPU (``render`` returns the slot it rendered into, ``gather(slot)``
+        """``pipelined``: two local framebuffers (and, for N > 1, two gather buffers), so that the collective of one render can run
+        while the next render is already on the GPU -- and consecutive renders overlap: the next image's first trace launch fills
+        the machine while this image's last one runs its paths out (``render`` returns the slot it rendered into, ``gather(slot)``
         takes it; see ``bench.py``).  Every render must then start at frame 0 or continue its own slot's frames."""
         self.dev, self.world, self.rank = dev, int(world), int(rank)
         self.width, self.height = int(width), int(height)
         self.plan = StripePlan(height, stripe_rows, world)
         self.cuda = torch.device("cuda", torch.cuda.current_device())
-        # All of this rank's shim work (renders, assembly) runs on ONE dedicated torch stream whose
-        # handle is a real hipStream_t (torch's default stream reports 0, which the shim would read
-        # as "restore your own stream").  Every hand-over between that stream and the stream torch
-        # ops / the collective run on is an event wait (wait_stream), never a host sync.
-        self.stream = torch.cuda.Stream(device=self.cuda)
-        shim.check(shim.load().pt_device_set_stream(dev._h, self.stream.cuda_stream))
-        self.pipelined = bool(pipelined) and self.world > 1
+        # The device handle keeps its OWN stream and render lanes (pt_shim.h): consecutive renders then overlap on the GPU --
+        # the next image's first trace launch fills the machine while this image's last paths drain -- which a stream shared
+        # with torch would serialise.  Every hand-over between the shim and the stream torch ops / the collective run on is a
+        # device-side event wait (Device.waitStream / waitHipEvent, SyncObject.waitOnStream), never a host sync.
+        self.pipelined = bool(pipelined)
         nslots = 2 if self.pipelined else 1
         self._locals = [torch.zeros((self.plan.slab_rows, self.width, 4), dtype=torch.float32, device=self.cuda) for _ in range(nslots)]
         self.local = self._locals[0]
-        self.stream.wait_stream(torch.cuda.current_stream(self.cuda))  # the zero fill precedes the first render
+        dev.waitStream(torch.cuda.current_stream(self.cuda).cuda_stream)  # the zero fill precedes the first render
         self.renderer = Renderer(dev, triangles, materials, width, height, n_ranks=world, rank=rank,
                                  stripe_rows=stripe_rows, fb_device_ptr=self.local.data_ptr(), want_stats=want_stats)
         assert self.renderer.local_rows == self.plan.local_rows(rank)
@@ -109,8 +108,8 @@ class StripeImage:
             b = adl.Buffer(dtype=adl.float4)
             b.setRawPtr(dev, t.data_ptr(), max(self.renderer.local_pixels, 1))
             self._fbs.append(b)
-        # per slot: "its render is done" (recorded on the shim stream), "its collective has read it" (on torch's stream)
-        self._rendered = [torch.cuda.Event() for _ in range(nslots)]
+        # per slot: "its render is done" (a shim event, behind the render's last fold), "its collective has read it" (on torch's stream)
+        self._rendered = [adl.SyncObject(dev) for _ in range(nslots)]
         self._collected = [None] * nslots
         self._slot = 0       # the slot the next render goes to
         self._last = 0       # the slot the last render went to
@@ -136,20 +135,19 @@ class StripeImage:
                 self._gbufs.append(g)
 
     def render(self, frames: int, *, frame_begin: Optional[int] = None, max_bounces: int = 16) -> int:
-        """Enqueue frames on the shim stream; returns the slot rendered into (always 0 unless ``pipelined``).
+        """Enqueue frames; returns the slot rendered into (always 0 unless ``pipelined``).
         ``self.local`` may be consumed by torch ops on the current stream after ``ready()`` (or ``gather()``),
         without a host synchronisation."""
         slot = self._slot
         if self.pipelined:
             # only the collective that last read THIS slot has to be over; the other slot's may still be running
             if self._collected[slot] is not None:
-                self.stream.wait_event(self._collected[slot])
+                self.dev.waitHipEvent(self._collected[slot].cuda_event)
         else:
             # torch work already queued on the current stream that touches self.local (a previous
             # gather reading it, a user op) must finish before the render overwrites it
-            self.stream.wait_stream(torch.cuda.current_stream(self.cuda))
-        self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces, fb=self._fbs[slot])
-        self._rendered[slot].record(self.stream)
+            self.dev.waitStream(torch.cuda.current_stream(self.cuda).cuda_stream)
+        self.renderer.render(frames, frame_begin=frame_begin, max_bounces=max_bounces, fb=self._fbs[slot], sync=self._rendered[slot])
         self._last = slot
         self.local = self._locals[slot]
         if self.pipelined:
@@ -157,22 +155,19 @@ class StripeImage:
         return slot
 
     def ready(self) -> torch.Tensor:
-        """Order torch's current stream after everything enqueued on the shim stream so far and
-        return the local framebuffer tensor (device-side wait only)."""
-        torch.cuda.current_stream(self.cuda).wait_stream(self.stream)
+        """Order torch's current stream after the last render and return the local framebuffer tensor
+        (device-side wait only)."""
+        self._rendered[self._last].waitOnStream(torch.cuda.current_stream(self.cuda).cuda_stream)
         return self.local
 
     def gather(self, slot: Optional[int] = None) -> Optional[torch.Tensor]:
         """Assemble the full image of the last render (or of ``slot``) on rank 0 (returns it there; None elsewhere).
 
         Pipelined use: ``s = img.render(...)`` of the NEXT image first, then ``img.gather(previous_slot)``: the
-        collective runs on torch's stream beside that render, the assembly kernel follows it on the shim stream."""
+        collective runs on torch's stream beside that render, the assembly kernel follows it on a stream of its own."""
         cur = torch.cuda.current_stream(self.cuda)
         slot = self._last if slot is None else int(slot)
-        if self.pipelined:
-            cur.wait_event(self._rendered[slot])   # this slot's render -> collective (a later render may be in flight)
-        else:
-            cur.wait_stream(self.stream)           # renders -> collective / consumer
+        self._rendered[slot].waitOnStream(cur.cuda_stream)   # this slot's render -> collective / consumer (a later render may be in flight)
         if self.world == 1:
             self.image = self._locals[slot][: self.height]
             return self.image
@@ -207,5 +202,6 @@ class StripeImage:
                 b.release()
         self._gbufs, self._ibuf, self._fbs = [], None, self._fbs[:1]
         self.renderer.release()
-        # hand the device handle back to its own stream before the torch stream can die
-        shim.check(shim.load().pt_device_set_stream(self.dev._h, None))
+        for e in self._rendered:
+            e.release()
+        self._rendered = []

@@ -17,11 +17,12 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE, PT_ERR_TRAVERSAL = range(1, 9)
 PT_INFO_NAME, PT_INFO_BOARD, PT_INFO_VENDOR, PT_INFO_VERSION = range(4)
 PT_OPT_BATCH_FRAMES, PT_OPT_CHUNK_FRAMES, PT_OPT_PROFILE_RETURN_TIME = 0, 1, 2   # (3 is not assigned)
-PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT_BVH_STACK_LIMIT = 4, 5, 6, 7, 8
+PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT_BVH_STACK_LIMIT, PT_OPT_RENDER_LANES, PT_OPT_CHECKPOINT = 4, 5, 6, 7, 8, 9, 10
+PT_SHIM_ABI_VERSION = 2  # include/pt_shim.h; load() refuses a library of another version
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64
 PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 8
-PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS, PT_STAT_BVH_MAX_STACK = 2, 3, 4, 5, 6
+PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS, PT_STAT_BVH_MAX_STACK, PT_STAT_CARRIED = 2, 3, 4, 5, 6, 7
 PT_PROF_TRACE, PT_PROF_FOLD = 0, 1
 PT_STREAM_LEGACY = 1  # hipStreamLegacy: how a caller names the legacy default stream to pt_device_set_stream
 
@@ -67,9 +68,14 @@ SIGNATURES = {
     "pt_device_mem_size": (_c.c_uint64, [_H]),
     "pt_device_used_memory": (_c.c_uint64, [_H]),
     "pt_device_peak_memory": (_c.c_uint64, [_H]),
+    "pt_device_workspace_memory": (_c.c_uint64, [_H]),
+    "pt_device_reserve_staging": (_c.c_int, [_H, _c.c_size_t]),
     "pt_device_num_cus": (_c.c_int, [_H]),
     "pt_device_set_stream": (_c.c_int, [_H, _c.c_void_p]),
     "pt_device_get_stream": (_c.c_void_p, [_H]),
+    "pt_device_wait_stream": (_c.c_int, [_H, _c.c_void_p]),
+    "pt_device_wait_hip_event": (_c.c_int, [_H, _c.c_void_p]),
+    "pt_event_wait_on": (_c.c_int, [_H, _c.c_void_p]),
     "pt_sync": (_c.c_int, [_H]),
     "pt_flush": (_c.c_int, [_H]),
     "pt_device_set_option": (_c.c_int, [_H, _c.c_int, _c.c_int64]),
@@ -99,6 +105,7 @@ SIGNATURES = {
     "pt_render_frames": (_c.c_int, [_H, _H, _H, _H, _c.POINTER(RenderParams), _H, _H]),
     "pt_profile_enable": (_c.c_int, [_H, _c.c_int]),
     "pt_profile_query": (_c.c_int, [_H, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
+    "pt_profile_query_union": (_c.c_int, [_H, _c.c_int, _c.POINTER(_c.c_double)]),
     "pt_profile_reset": (_c.c_int, [_H]),
     "pt_assemble_stripes": (_c.c_int, [_H, _H, _H, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _H]),
     "pt_assemble_stripes_on": (_c.c_int, [_H, _H, _H, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -127,6 +134,9 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = ABI drift; do not mask it
             fn.restype = res
             fn.argtypes = args
+        if lib.pt_abi_version() != PT_SHIM_ABI_VERSION:
+            raise ShimError(PT_ERR_INVALID, "libptshim.so speaks ABI version %d, this binding %d: rebuild (__graft_entry__.build())"
+                            % (lib.pt_abi_version(), PT_SHIM_ABI_VERSION))
         _lib = lib
     return _lib
 

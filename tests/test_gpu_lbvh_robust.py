@@ -82,32 +82,94 @@ def test_deep_hierarchy_is_searched_exactly_and_the_stack_depth_is_reported(devi
 
 
 def test_a_truncated_search_fails_the_render(device, oracle):
-    """PT_OPT_BVH_STACK_LIMIT lowers the stack's capacity until ordinary rays overflow it: the render must fail with
-    PT_ERR_TRAVERSAL (never return pixels of a search that lost a subtree), and succeed bit-exactly again at full capacity."""
-    from oclpathtracer_amd import scene, shim
+    """PT_OPT_BVH_STACK_LIMIT lowers the stack's capacity until ordinary rays overflow it: the render must be reported as
+    failed with PT_ERR_TRAVERSAL (never return pixels of a search that lost a subtree), and succeed bit-exactly again at full
+    capacity.  Renders are asynchronous and no render waits for the device to read the flag: the error is
+    DEFERRED to the first call that observes the device -- pt_sync, an event wait, a blocking map, or the next render."""
+    from oclpathtracer_amd import adl, scene, shim
     from oclpathtracer_amd.render import Renderer
 
     tris, mats = scene.make_soup(20_000)
     W, H, frames = 64, 32, 2
     device.setOption(shim.PT_OPT_ACCEL, 2)
     r = Renderer(device, tris, mats, W, H, want_stats=True)
+    ev = adl.SyncObject(device)
     try:
         device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 1)
+        # (1) pt_sync reports it; the render call itself only enqueues
+        r.render(frames, frame_begin=0)
+        with pytest.raises(shim.ShimError) as err:
+            device.waitForCompletion()
+        assert err.value.code == shim.PT_ERR_TRAVERSAL, err.value
+        assert "stack" in str(err.value)
+        device.waitForCompletion()          # reporting cleared the word: the handle is usable again
+        # (2) an event wait reports it
+        r.render(frames, frame_begin=0, sync=ev)
+        with pytest.raises(shim.ShimError) as err:
+            ev.waitForCompletion()
+        assert err.value.code == shim.PT_ERR_TRAVERSAL, err.value
+        # (3) the next render reports it (and renders nothing): the failed render has certainly finished once a
+        # host-side wait that does NOT check -- a plain stream query through an unrelated event -- has returned
+        r.render(frames, frame_begin=0)
+        fence = adl.SyncObject(device)
+        tmp = adl.Buffer(device, 4, np.int32)
+        tmp.write(np.zeros(4, np.int32), 4, syncObj=fence)   # enqueued behind the render on the handle's stream
+        while not fence.isComplete():
+            pass
+        device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 64)
         with pytest.raises(shim.ShimError) as err:
             r.render(frames, frame_begin=0)
         assert err.value.code == shim.PT_ERR_TRAVERSAL, err.value
-        assert "stack" in str(err.value)
+        tmp.release()
+        fence.release()
+        # (4) a blocking map reports it
+        device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 1)
+        r.render(frames, frame_begin=0)
+        with pytest.raises(shim.ShimError):
+            r.fb.getHostPtr(blocking=True)
         device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 64)
         r.render(frames, frame_begin=0)
         got = r.read()
     finally:
         device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 64)
         device.setOption(shim.PT_OPT_ACCEL, 0)
+        try:
+            device.waitForCompletion()
+        except shim.ShimError:
+            pass
+        ev.release()
         r.release()
     want = oracle.render(tris, mats, W, H, frames)
     assert_fb_equal(got, want, "after the limit was restored")
     with pytest.raises(shim.ShimError):
         device.setOption(shim.PT_OPT_BVH_STACK_LIMIT, 65)
+
+
+def test_lbvh_renders_do_not_wait_for_the_device(device):
+    """an LBVH render used to end in hipStreamSynchronize to read the traversal flag, which serialised
+    the pipelined N-rank loop (render k+1 could not be enqueued beside gather k).  Now the call returns while the GPU is
+    still rendering: several seconds of LBVH work are enqueued in a fraction of the time they take to run."""
+    import time
+
+    from oclpathtracer_amd import scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = scene.make_soup(100_000)
+    r = Renderer(device, tris, mats, 512, 512)
+    try:
+        r.render(1, frame_begin=0)            # builds the hierarchy (that does wait, once per scene)
+        device.waitForCompletion()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            r.render(16, frame_begin=0)
+        t_enqueue = time.perf_counter() - t0
+        device.waitForCompletion()
+        t_total = time.perf_counter() - t0
+    finally:
+        r.release()
+    print("four LBVH renders: enqueued in %.2f ms, finished after %.1f ms" % (t_enqueue * 1e3, t_total * 1e3))
+    assert t_total > 0.02, "workload too small to tell"
+    assert t_enqueue < 0.25 * t_total, (t_enqueue, t_total)
 
 
 def _horizon_tiles(delta, tile=0.3, glossy_every=3):

@@ -24,7 +24,9 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libptshim.so does not export %s" % n
     assert sorted(shim.SIGNATURES) == names, "shim.py binding and include/pt_shim.h disagree"
-    assert shim.load().pt_abi_version() == 1
+    assert shim.load().pt_abi_version() == shim.PT_SHIM_ABI_VERSION == 2
+    hdr = open(os.path.join(ROOT, "include", "pt_shim.h")).read()
+    assert re.search(r"#define\s+PT_SHIM_ABI_VERSION\s+2\b", hdr)
 
 
 def test_struct_layouts_match_header():
