@@ -302,7 +302,10 @@ enum {
     PT_STAT_BVH_NODES = 2, PT_STAT_BVH_TRIS = 3, PT_STAT_BVH_STEPS = 4 /* node phases */, PT_STAT_BVH_TRI_STEPS = 5,
     PT_STAT_BVH_MAX_STACK = 6 /* the deepest traversal stack any ray needed (a maximum, not a sum; capacity: 64) */,
     PT_STAT_CARRIED = 7 /* samples (paths under way + samples not yet started) that checkpointed launches handed to their successors */,
-    PT_STAT_WORDS = 8
+    /* PT_OPT_BVH_TALLY renders only: accepted closest hits at cos(incidence) < 1e-2, i.e. outside the range over which the LBVH's box
+     * margin is argued conservative (csrc/pt_bvh.hip) -- the measured exposure of a scene to the LBVH's one theoretical caveat */
+    PT_STAT_BVH_GRAZING = 8,
+    PT_STAT_WORDS = 16
 };
 
 int pt_render_frames(pt_device_t dev, pt_buffer_t triangles, pt_buffer_t materials,

@@ -92,7 +92,7 @@ struct PtTraceParams {
     float* rad1;                  // sample.  A path's `fl` is its frame counted from the render's first (frame_begin - chunk_f0 is that frame's
                                   // absolute number); chunk c of the render is frames [c S, (c + 1) S) and goes to slot (c + ring_phase / S) % 2,
                                   // so a path CARRIED into the next launch (below) still stores to its own chunk's slot
-    unsigned int* batch_counter;  // the work queue (two cache lines, PT_QUEUE_STOP_WORD); zero at the launch (the fold kernel that follows the trace launch on its stream resets it: PtFoldParams::reset_counter)
+    unsigned int* batch_counter;  // the work queue (PT_QUEUE_WORDS words: sharded counters + stop word); zero at the launch (the fold kernel that follows the trace launch on its stream resets it: PtFoldParams::reset_counter)
     unsigned long long* stats;    // may be null: [0] samples, [1] rays
     int32_t width, height;
     float inv_width, inv_height, aspect;  // 1.0f / W, 1.0f / H, (float)W / (float)H (IEEE, host-computed: GenerateColors.cl:266-267)
@@ -105,7 +105,7 @@ struct PtTraceParams {
     int32_t max_bounces, ntri, nmat;
     int32_t stripe_rows, n_ranks, rank;
     uint32_t npix_local;
-    uint32_t batches_per_frame, total_batches;   // total_batches: those of this launch that come off the dynamic queue
+    uint32_t batches_per_frame, total_batches;
     uint32_t batch;               // samples per work-queue grab: 64, 128 or 256 (<= PT_TRACE_BATCH)
     float quad_delta1;            // quad mode 2 (pt_quad2_pass1): slack of the shared-u bounds
     float ray_radius;             // quad modes 2, 3: rays with |origin - eye|_inf above this keep every triangle
@@ -131,12 +131,13 @@ struct PtTraceParams {
     uint32_t* carry;              // PT_CARRY_STRIDE_DW dwords per wave of the grid
     uint32_t carry_in_waves;
     uint32_t carry_out;
-    // how batches are dealt to waves (pt_queue_refill): numbered over the whole render, this launch's chunk is [g_begin, g_static +
-    // total_batches); [g_begin, g_static) goes as static lists with stride n_waves (the grid, in waves), the rest comes off the queue
-    // on batch_counter; g_old_static: where the static lists of the PREVIOUS launch's chunk ended (lists a checkpoint left unfinished)
-    uint32_t n_waves, g_begin, g_static, g_old_static;
 };
-#define PT_QUEUE_STOP_WORD 32     // a work queue is two 128-byte lines: [0] the counter, [PT_QUEUE_STOP_WORD] the stop word of checkpointed launches
+// a work queue: PT_QUEUE_SHARDS counters and, behind them, the stop word of checkpointed launches (one bit per shard found empty), each on
+// a line of its own, PT_QUEUE_SHARD_WORDS apart (4 KiB + 128 B: whatever the address-to-channel map is, neighbours differ in both fields)
+#define PT_QUEUE_SHARDS 8
+#define PT_QUEUE_SHARD_WORDS 1056
+#define PT_QUEUE_STOP_WORD (PT_QUEUE_SHARDS * PT_QUEUE_SHARD_WORDS)
+#define PT_QUEUE_WORDS ((PT_QUEUE_SHARDS + 1) * PT_QUEUE_SHARD_WORDS)
 #define PT_CARRY_RECORDS 64       // a wave stops with an empty pool and parks its (at most 64) live paths
 #define PT_CARRY_STRIDE_DW (16 + PT_CARRY_RECORDS * 15)   // header (paths, pix, end, ring frame, absolute frame) + the parked-path record as arrays
 

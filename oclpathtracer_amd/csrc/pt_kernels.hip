@@ -1036,54 +1036,44 @@ struct PtWaveQueue {  // wave-uniform (SGPRs): the wave's current range [pix, en
     unsigned pix, end, frame;   // frame: counted from the render's first frame (what a path keeps as `fl`)
     unsigned row, col;       // local row / column of `pix`, kept incrementally: no per-lane division
     unsigned sl, within;     // row = sl * stripe_rows + within (the stripe of the multi-GPU split)
-    unsigned g;              // the next batch of the wave's static list (pt_queue_refill), or:
+    unsigned g;              // the shard of the queue the wave takes its batches from, or PT_Q_EMPTY (pt_queue_refill)
 };
 
-#define PT_Q_LIST_DONE 0xfffffffeu   // the list is done, the wave takes batches off the dynamic queue
-#define PT_Q_EMPTY 0xffffffffu       // ... and a grab has found that empty too
+#define PT_Q_EMPTY 0xffffffffu   // PtWaveQueue::g once the wave has found every shard of the queue empty
 
 // Makes [q.pix, q.end) non-empty when the current batch is used up; false when there is nothing (more) to start in this launch.
-// The batches (128 or 256 consecutive pixels of one frame) of the whole RENDER are numbered frame-major, g = frame x batches_per_frame
-// + i; a launch's chunk is [g_begin, g_limit).  They are dealt to the waves in two ways:
-//  * STATIC LISTS for the first part of a chunk, [g_begin, g_static) (checkpointed launches; n_waves != 0): wave w of the W in the grid
-//    owns g_begin + w, + W, + 2W, ...  No atomic, no round trip to the L2, nothing for 8 192 waves that start a launch together to
-//    queue up behind (measured: 0.17 ms per launch).  Within a frame the pixel batches are rotated by a frame-dependent amount, so a
-//    wave's batches wander over the image and the lists cost the same to a few per cent;
-//  * the DYNAMIC QUEUE for the rest, [g_static, g_limit): one atomic per batch on the launch's counter -- the waves that finish their
-//    lists early take more of it, so the launch's work runs out everywhere at about the same time.  Whoever takes its last batch
-//    raises the queue's STOP word (a cache line of its own behind the counter's: what the waves of a checkpointed launch poll,
-//    pt_queue_next, instead of the line the atomic adds go to).
-// A wave that was stopped inside its list goes on with it in the next launch (g < g_begin there: the previous chunk's, "old"), up
-// to that chunk's static limit g_old_static, and then starts this chunk's.  The LBVH kernel and PT_OPT_CHECKPOINT 0 have no lists
-// (g_static = g_begin): every batch comes off the queue, which a launch that runs every path out by itself needs.
+// The batches of a launch's chunk (128 or 256 consecutive pixels of one frame, numbered frame-major) come off a SHARDED queue:
+// PT_QUEUE_SHARDS counters, each on a cache line of its own; shard s deals the batches s, s + NS, s + 2 NS, ...  One counter for
+// 8 192 waves is an L2 channel's atomic unit doing nothing else -- at 128 samples per batch a 16-frame launch is an atomic every
+// 14 ns, about what the unit serves, and the waves of a launch start TOGETHER, so their grabs arrive in bursts (a wave waits for its
+// turn: measured ~50 us per launch, profiles/r04/queue_shards.txt).  A wave stays with its shard (the wave's number mod NS at
+// first) and moves on to the next when it is used up; a shard found empty is marked in the queue's STOP word (one bit per shard,
+// on a line of its own), which every wave polls at its fresh phases anyway (pt_queue_next) and which spares the others the grab.
+// All bits set = the launch has handed out its last batch.
 template <bool LATE>
-PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q)
+PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, unsigned empty_mask)
 {
     const pt_kargs_p K = pt_kargs();
     if (q.pix != q.end) return true;
-    unsigned g = q.g;
-    if (g < PT_Q_LIST_DONE) {
-        // a batch of the wave's list: this chunk's, or still the previous chunk's (g < g_begin), which ends at g_old_static -- then
-        // this chunk's begins, at the wave's own number; the value kept is always a batch still to do, or one of the two marks
-        unsigned nx = g + PT_ARG(n_waves);
-        if (g < PT_ARG(g_begin) && nx >= PT_ARG(g_old_static))
-            nx = PT_ARG(g_begin) + blockIdx.x * (PT_TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        q.g = nx < PT_ARG(g_static) ? nx : PT_Q_LIST_DONE;
-    } else {
-        if (g == PT_Q_EMPTY) return false;
-        unsigned b = 0;
-        if (lane == 0) b = atomicAdd(PT_ARG(batch_counter), 1u);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (PT_ARG(carry_out) != 0u && b + 1u >= PT_ARG(total_batches) && lane == 0u)
-            __hip_atomic_store(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b >= PT_ARG(total_batches)) { q.g = PT_Q_EMPTY; return false; }
-        q.g = PT_Q_LIST_DONE;
-        g = PT_ARG(g_static) + b;
+    if (q.g == PT_Q_EMPTY) return false;
+    const unsigned total = PT_ARG(total_batches);
+    unsigned sh = q.g, b = 0u;
+    bool got = false;
+    for (unsigned tries = 0u; tries < PT_QUEUE_SHARDS && total != 0u; ++tries, sh = (sh + 1u) & (PT_QUEUE_SHARDS - 1u)) {
+        if ((empty_mask >> sh) & 1u) continue;
+        unsigned k = 0u;
+        if (lane == 0) k = atomicAdd(PT_ARG(batch_counter) + sh * PT_QUEUE_SHARD_WORDS, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        b = k * PT_QUEUE_SHARDS + sh;
+        if (b < total) { got = true; break; }
+        empty_mask |= 1u << sh;
+        if (lane == 0u) atomicOr(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u << sh);
     }
-    const unsigned f = g / PT_ARG(batches_per_frame);
-    unsigned bi = g - f * PT_ARG(batches_per_frame) + (f * 40503u) % PT_ARG(batches_per_frame);   // (f < 32 768: no overflow)
-    if (bi >= PT_ARG(batches_per_frame)) bi -= PT_ARG(batches_per_frame);
-    q.frame = f;
+    if (!got) { q.g = PT_Q_EMPTY; return false; }
+    q.g = sh;
+    const unsigned f = b / PT_ARG(batches_per_frame);
+    const unsigned bi = b - f * PT_ARG(batches_per_frame);
+    q.frame = PT_ARG(chunk_f0) + f;
     q.pix = bi * PT_ARG(batch);
     const unsigned e = q.pix + PT_ARG(batch);
     q.end = e < PT_ARG(npix_local) ? e : PT_ARG(npix_local);
@@ -1177,7 +1167,6 @@ PTK_DEV void pt_carry_store(uint32_t* region, unsigned lane, const float4* pool,
         region[1] = q.pix;
         region[2] = q.end;
         region[3] = q.frame;
-        region[7] = q.g;
         // the wave's tallies travel with the checkpoint and reach the stats buffer at the end of the render's last launch, where the
         // waves leave one by one: 8 192 waves leaving TOGETHER, two or three atomics each on the same line, measured 0.25 ms per launch
         region[4] = n_rays;
@@ -1200,7 +1189,6 @@ PTK_DEV void pt_carry_load(const PtTraceParams& P, const uint32_t* region, unsig
     q.pix = __builtin_amdgcn_readfirstlane(region[1]);
     q.end = __builtin_amdgcn_readfirstlane(region[2]);
     q.frame = __builtin_amdgcn_readfirstlane(region[3]);
-    q.g = __builtin_amdgcn_readfirstlane(region[7]);
     q.row = q.pix / (unsigned)PT_ARG(width);
     q.col = q.pix - q.row * (unsigned)PT_ARG(width);
     q.sl = q.row / (unsigned)PT_ARG(stripe_rows);
@@ -1224,22 +1212,22 @@ PTK_DEV void pt_carry_load(const PtTraceParams& P, const uint32_t* region, unsig
 
 // The wave is at a fresh-phase boundary (its pool is empty, some lane is dead).  1: [q.pix, q.end) holds samples to start;
 // 0: nothing left to start (the classic end: the wave runs its last paths out); 2: STOP -- this launch ends with a
-// checkpoint (carry_out): the launch's queue has handed out its last batch (its stop word is up: one line of its own, written
-// once, polled by one lane per wave and fresh phase), and this wave holds nothing of the PREVIOUS launch's chunk any more,
-// whose fold follows this launch.
+// checkpoint (carry_out): its queue has handed out the last batch (every shard's bit of the stop word is up: a line of its
+// own, polled by one lane per wave and fresh phase), and this wave holds nothing of the PREVIOUS launch's chunk any more, whose
+// fold follows this launch.
 template <bool LATE>
 PTK_DEV int pt_queue_next(const PtTraceParams& P, unsigned lane, PtWaveQueue& q, const PtPath& s, bool alive)
 {
     const pt_kargs_p K = pt_kargs();
+    unsigned empty_mask = 0u;
     if (PT_ARG(carry_out) != 0u) {
-        unsigned stop = 0u;
-        if (lane == 0u) stop = __hip_atomic_load(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stop = (unsigned)__builtin_amdgcn_readfirstlane(stop);
-        // (of the previous chunk: a batch under way, batches of the list not yet begun, paths in lanes -- the pool is empty)
-        if (stop != 0u && !(q.pix != q.end && q.frame < PT_ARG(chunk_f0)) && q.g >= PT_ARG(g_begin) && __ballot(alive && s.fl < PT_ARG(chunk_f0)) == 0ull)
+        if (lane == 0u) empty_mask = __hip_atomic_load(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        empty_mask = (unsigned)__builtin_amdgcn_readfirstlane(empty_mask);
+        // (of the previous chunk: a batch under way, paths in lanes -- the pool is empty)
+        if (empty_mask == (1u << PT_QUEUE_SHARDS) - 1u && !(q.pix != q.end && q.frame < PT_ARG(chunk_f0)) && __ballot(alive && s.fl < PT_ARG(chunk_f0)) == 0ull)
             return 2;
     }
-    return pt_queue_refill<LATE>(P, lane, q) ? 1 : 0;
+    return pt_queue_refill<LATE>(P, lane, q, empty_mask) ? 1 : 0;
 }
 
 // FRESH phase: every lane is dead (its path parked); the next (up to) 64 samples of the wave's range start
@@ -1326,13 +1314,11 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
     unsigned n_rays = 0, n_samples = 0, n_carried = 0;   // (n_carried: samples this wave's checkpoints have handed on, PT_STAT_CARRIED)
     // checkpointed launches: resume what the previous launch of the render left in this wave's region
     // (the wave's number through readfirstlane: to the compiler threadIdx.x >> 6 differs between lanes, and so would everything below)
-    // the wave's list of this chunk begins at its own number (a checkpoint may say otherwise)
-    q.g = P.g_begin + blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg;
-    if (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg < P.carry_in_waves) {
+    // checkpointed launches: resume what the previous launch of the render left in this wave's region
+    // (the wave's number through readfirstlane: to the compiler threadIdx.x >> 6 differs between lanes, and so would everything below)
+    if (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg < P.carry_in_waves)
         pt_carry_load<true>(P, P.carry + (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) * PT_CARRY_STRIDE_DW, lane, s, alive, q, n_rays, n_samples, n_carried);
-        if (q.g >= PT_Q_LIST_DONE) q.g = P.g_begin + blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg;   // (it had finished the previous chunk's list)
-    }
-    if (q.g >= P.g_begin && q.g >= P.g_static) q.g = PT_Q_LIST_DONE;   // (no list for this wave in this chunk: every batch off the queue)
+    q.g = (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) & (PT_QUEUE_SHARDS - 1u);   // the wave's first shard of this launch's queue
 #if PT_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0, c_p1 = 0;
 #endif
@@ -1498,7 +1484,7 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
 {
     const pt_kargs_p K = pt_kargs();
     unsigned long long need = __ballot(!alive);
-    while (need != 0ull && pt_queue_refill<LATE>(P, lane, q)) {
+    while (need != 0ull && pt_queue_refill<LATE>(P, lane, q, 0u)) {
         const unsigned n_need = (unsigned)__popcll(need);
         const unsigned avail = q.end - q.pix;
         const unsigned take = n_need < avail ? n_need : avail;
@@ -1820,7 +1806,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     }
     pt_const_f32p bigT = (pt_const_f32p)(const float*)P.bigtab;
 
-    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, PT_Q_LIST_DONE };   // (no static lists here: every batch comes off the queue)
+    PtWaveQueue q = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, (blockIdx.x * (PT_TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) & (PT_QUEUE_SHARDS - 1u) };
     bool alive = false;  // the lane holds a path
     bool trav = false;   // ... whose closest-hit search is in progress
     PtPath s;
@@ -1831,7 +1817,7 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     PtBvhLane L;  // the search's state
     L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1;
     L.gbase = L.gm = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
-    unsigned c_nodes = 0, c_leaves = 0, c_maxsp = 0;
+    unsigned c_nodes = 0, c_leaves = 0, c_maxsp = 0, c_graze = 0;
     unsigned long long c_steps = 0, c_tsteps = 0;
 
     for (;;) {
@@ -1843,6 +1829,15 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             }
             const unsigned long long shaded = __ballot(alive && !trav);
             n_rays += (unsigned)__popcll(shaded);
+            if (TALLY && alive && !trav && L.hidx >= 0) {
+                // the LBVH's exposure (pt_bvh.hip: no finite box margin is PROVABLY conservative for rays within a fraction of a degree
+                // of a triangle's plane; the margin covers cos(incidence) >= 1e-2 with a factor 10 to spare): accepted hits that lie
+                // outside that range.  cos(incidence) = |dir . n| / |n|, n = e2 x e1 (the prepared record's), |dir| = 1.
+                const PtPrepTriangle* t = P.tris + L.hidx;
+                const float nx = t->n[0], ny = t->n[1], nz = t->n[2];
+                const float dn = __builtin_fabsf(s.d.x * nx + s.d.y * ny + s.d.z * nz);
+                if (dn < 1.0e-2f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz)) ++c_graze;
+            }
             if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx);
             n_samples += (unsigned)__popcll(shaded & ~__ballot(alive));
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
@@ -1870,14 +1865,16 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     }
 
     if (TALLY && P.stats) {
-        unsigned long long n = c_nodes, l = c_leaves;
+        unsigned long long n = c_nodes, l = c_leaves, gz = c_graze;
         for (int off = 32; off > 0; off >>= 1) {
             n += __shfl_down(n, off);
             l += __shfl_down(l, off);
+            gz += __shfl_down(gz, off);
         }
         if (lane == 0) {
             atomicAdd(&P.stats[2], n);
             atomicAdd(&P.stats[3], l);
+            if (gz) atomicAdd(&P.stats[8], gz);   // PT_STAT_BVH_GRAZING
             atomicAdd(&P.stats[4], c_steps);
             atomicAdd(&P.stats[5], c_tsteps);
         }
@@ -2022,8 +2019,10 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(const PtFoldParams P)
     // a rank's share of a multi-GPU render has too few pixels to fill the chip with one lane per pixel
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid == 0u) {   // (the trace launches that used them have completed: stream order)
-        if (P.reset_counter != nullptr) P.reset_counter[0] = P.reset_counter[PT_QUEUE_STOP_WORD] = 0u;
-        if (P.reset_counter2 != nullptr) P.reset_counter2[0] = P.reset_counter2[PT_QUEUE_STOP_WORD] = 0u;
+        for (int k = 0; k <= PT_QUEUE_SHARDS; ++k) {   // (the shards' counters and the stop word behind them)
+            if (P.reset_counter != nullptr) P.reset_counter[k * PT_QUEUE_SHARD_WORDS] = 0u;
+            if (P.reset_counter2 != nullptr) P.reset_counter2[k * PT_QUEUE_SHARD_WORDS] = 0u;
+        }
     }
     const unsigned lp = tid / 3u, ch = tid - 3u * lp;
     if (lp >= P.npix_local) return;

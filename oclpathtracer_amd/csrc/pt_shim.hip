@@ -161,7 +161,7 @@ struct pt_device_s {
 #define PT_RING_SLOTS 2
 #define PT_DEFAULT_SLOT_BYTES ((size_t)192 << 20)   // sixteen 1024 x 1024 frames of 12-byte radiance
 #define PT_QUEUE_COUNTERS 64                        // (the last two are the lanes' draining launches')
-#define PT_QUEUE_STRIDE 64                          // words: two 128-byte lines per queue (counter, stop word: PT_QUEUE_STOP_WORD)
+#define PT_QUEUE_STRIDE PT_QUEUE_WORDS              // words per queue: sharded counters + stop word (pt_kernels.h)
 
 static int prof_begin(pt_device_s* d, int kind, hipStream_t st, hipEvent_t* stop_out)
 {
@@ -1116,8 +1116,9 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
     // L2 atomic unit saturates -- measured +30 % launch time)
     uint32_t batch = PT_TRACE_BATCH;
     while (batch > 128u && chunk_samples / batch < 64u * resident_waves) batch >>= 1;
+    if (getenv("PT_SHIM_BATCH")) batch = (uint32_t)std::max(64, atoi(getenv("PT_SHIM_BATCH")));   // (experiments)
     const uint32_t bpf = (npix + batch - 1) / batch;
-    if ((uint64_t)bpf * (uint64_t)rp.frame_count > 0xffffffffull) return fail(PT_ERR_INVALID, "render too large: more than 2^32 batches");
+    if ((uint64_t)bpf * (uint64_t)chunk + PT_QUEUE_SHARDS > 0xffffffffull) return fail(PT_ERR_INVALID, "chunk too large");
 
     PtTraceParams tp;
     memset(&tp, 0, sizeof tp);
@@ -1171,10 +1172,12 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         const uint64_t blocks_needed = ((uint64_t)bpf * (uint64_t)chunk + wg_waves - 1) / wg_waves;
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
     }
-    const int ln = d->opt_lanes == 2 ? (int)(d->render_seq++ & 1u) : 0;
-    hipStream_t st = d->lane[ln];
     // checkpointed launches: the table kernels (the LBVH kernel's traversal state lives in LDS and scratch)
     const bool carry = d->opt_carry && !use_bvh;
+    // the lane: one per render when its launches are checkpointed (each resumes its predecessor); otherwise the CHUNKS alternate, so that
+    // chunk c+1's launch becomes resident while chunk c's runs its paths out (an LBVH launch's tail is milliseconds of falling lane use)
+    int ln = d->opt_lanes == 2 ? (int)(d->render_seq++ & 1u) : 0;
+    hipStream_t st = d->lane[ln];
     if (carry) {
         const size_t waves = (size_t)d->prop.multiProcessorCount * 8 * wg_waves;   // (no kernel has more than 8 workgroups per CU resident)
         if ((size_t)blocks * wg_waves > waves) return fail(PT_ERR_INVALID, "grid larger than the checkpoint regions");
@@ -1206,8 +1209,8 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
     // the slot is free again
     bool chained = false;   // this render's folds are behind the previous render's (on the other lane)
     auto fold = [&](int slot, int f0, int nf, unsigned int* reset, unsigned int* reset2) -> int {
-        const bool last = f0 + nf >= rp.frame_count, last_two = f0 + nf + chunk >= rp.frame_count;
-        if (!chained && d->fold_recorded[ln ^ 1]) HIP_TRY(hipStreamWaitEvent(st, d->ev_fold[ln ^ 1], 0));
+        const bool last = f0 + nf >= rp.frame_count || !carry, last_two = f0 + nf + chunk >= rp.frame_count;
+        if ((!chained || !carry) && d->fold_recorded[ln ^ 1]) HIP_TRY(hipStreamWaitEvent(st, d->ev_fold[ln ^ 1], 0));
         chained = true;
         PtFoldParams fp;
         fp.rad = slot ? tp.rad1 : tp.rad;
@@ -1222,7 +1225,7 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         HIP_TRY(ptk_fold(fp, st));
         if ((r = prof_end(st, pstop))) return r;
         // what other lanes wait for: the slot is free again (the next render's first two chunks), the fold chain's newest link (its
-        // first fold; lanes_join) -- only a render's last two folds can be either
+        // first fold; lanes_join) -- only a render's last two folds can be either when all its launches share a lane
         if (last_two) {
             HIP_TRY(hipEventRecord(d->ev_slot[slot], st));
             d->slot_recorded[slot] = true;
@@ -1234,7 +1237,6 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         }
         return PT_OK;
     };
-    uint32_t old_static = 0u;   // where the previous launch's static lists ended
     auto trace = [&](int f0, int nf, unsigned int* counter, bool carry_in, bool carry_out) -> int {
         tp.batch_counter = counter;
         tp.frame_begin = rp.frame_begin + f0;
@@ -1242,21 +1244,7 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         tp.chunk_f0 = (uint32_t)f0;
         tp.carry_in_waves = carry_in ? (uint32_t)(blocks * wg_waves) : 0u;
         tp.carry_out = carry_out ? 1u : 0u;
-        // batches are numbered over the whole render; a checkpointed launch deals the first 7/8 of its chunk as static lists (equally
-        // many per wave) and the rest through the queue, which balances the end of the launch (pt_queue_refill)
-        const uint32_t waves = (uint32_t)(blocks * wg_waves);
-        const uint64_t nb = (uint64_t)bpf * (uint64_t)nf;
-        // (static lists are an experiment that LOST, profiles/r04/static_lists.txt: 0 of 8 eighths of a chunk dealt statically 33.1 ms per
-        // configs[2] step, 4 of 8 37.5, 8 of 8 42.2 -- waves differ persistently in speed, a list cannot be taken over by another wave, and
-        // the laggards hold every launch's end back; PT_SHIM_STATIC_EIGHTHS re-runs it)
-        static const int eighths = getenv("PT_SHIM_STATIC_EIGHTHS") ? atoi(getenv("PT_SHIM_STATIC_EIGHTHS")) : 0;
-        const uint64_t nstatic = carry ? (nb * (uint64_t)eighths / 8) / waves * waves : 0;
-        tp.n_waves = waves;
-        tp.g_begin = (uint32_t)((uint64_t)bpf * (uint64_t)f0);
-        tp.g_static = tp.g_begin + (uint32_t)nstatic;
-        tp.g_old_static = old_static;
-        tp.total_batches = (uint32_t)(nb - nstatic);
-        old_static = tp.g_static;
+        tp.total_batches = (uint32_t)((uint64_t)bpf * (uint64_t)nf);
         int r = prof_begin(d, PT_PROF_TRACE, st, &pstop);
         if (r) return r;
         HIP_TRY(ptk_trace(tp, blocks, d->prep_det_bounded, quads, use_bvh, d->opt_tally != 0 && stats != nullptr, st));
@@ -1268,6 +1256,10 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         const uint64_t seq = d->chunk_seq++;
         const int slot = (int)(seq & 1u);
         unsigned int* counter = d->counters + (size_t)(seq % (PT_QUEUE_COUNTERS - 2)) * PT_QUEUE_STRIDE;
+        if (!carry && d->opt_lanes == 2 && c > 0) {
+            ln ^= 1;
+            st = d->lane[ln];
+        }
         // the slot must have been folded out (by the other lane, when this is one of a render's first two chunks)
         if (c < 2 && d->slot_recorded[slot]) HIP_TRY(hipStreamWaitEvent(st, d->ev_slot[slot], 0));
         if ((rc = trace(f0, nf, counter, carry && c > 0, carry))) return rc;

@@ -21,8 +21,8 @@ PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT
 PT_SHIM_ABI_VERSION = 2  # include/pt_shim.h; load() refuses a library of another version
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64
-PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 8
-PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS, PT_STAT_BVH_MAX_STACK, PT_STAT_CARRIED = 2, 3, 4, 5, 6, 7
+PT_STAT_SAMPLES, PT_STAT_RAYS, PT_STAT_WORDS = 0, 1, 16
+PT_STAT_BVH_NODES, PT_STAT_BVH_TRIS, PT_STAT_BVH_STEPS, PT_STAT_BVH_TRI_STEPS, PT_STAT_BVH_MAX_STACK, PT_STAT_CARRIED, PT_STAT_BVH_GRAZING = 2, 3, 4, 5, 6, 7, 8
 PT_PROF_TRACE, PT_PROF_FOLD = 0, 1
 PT_STREAM_LEGACY = 1  # hipStreamLegacy: how a caller names the legacy default stream to pt_device_set_stream
 

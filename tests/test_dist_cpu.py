@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 (and 3) gloo rehearsal of the stripe sharding + gather + assembly.
+"""N>1 path on CPU: world_size-2, 3 and 8 gloo rehearsal of the stripe sharding + gather + assembly.
 
 Each rank renders ITS rows with the CPU oracle (test infrastructure standing in for the GPU
 renderer, using the same StripePlan the GPU path uses), the slabs travel through
@@ -83,6 +83,22 @@ def test_gloo_stripes_gather_assemble(tmp_path, oracle, cornell, world, H, strip
     tris, mats = cornell
     want = oracle.render(tris, mats, W, H, frames).reshape(H, W, 4)
     got = np.load(out)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("H", [1024, 1000])
+def test_gloo_world8_bench_geometry(tmp_path, oracle, cornell, H):
+    """Eight rank PROCESSES (the N-rank path had never run with 8 ranks anywhere): bench.py's split -- 4-row stripes
+    dealt round-robin, BASELINE's image height (and one that leaves the last period of stripes incomplete: 1000 = 31 x 32 + 8,
+    ranks 2..7 own a stripe less than ranks 0 and 1, their slabs are zero-padded in the gather) -- at a small width; the slab
+    list of the gather, StripePlan.slab_rows and the assembly index math at world 8, bit for bit the one-process image."""
+    W, frames, world, stripe_rows = 8, 1, 8, 4
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), W, H, frames, stripe_rows, out), nprocs=world, join=True)
+    tris, mats = cornell
+    want = oracle.render(tris, mats, W, H, frames).reshape(H, W, 4)
+    got = np.load(out)
+    assert got.shape == want.shape
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 

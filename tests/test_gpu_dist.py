@@ -165,6 +165,40 @@ def test_configs3_geometry_gather_and_assembly_rehearsal(device, cornell, oracle
         assert_fb_equal(got[row].reshape(-1, 4), fb[row * w:(row + 1) * w], "2048^2 two-rank image, row %d" % row)
 
 
+def test_world4_pipelined_configs2_geometry(device, cornell, tmp_path):
+    """Four rank processes on the one MI355X (the box admits six processes on its card; eight ranks are the driver's to start):
+    BASELINE configs[2]'s image, bench.py's 4-row stripes, the pipelined loop -- every rank with its own device handle, staging
+    ring and render lanes beside the others' -- against the one-process image."""
+    from oclpathtracer_amd.render import Renderer
+
+    w, h, frames, stripe = 1024, 1024, 3, 4
+    tris, mats = cornell
+    r = Renderer(device, tris, mats, w, h)
+    try:
+        r.render(frames)
+        want = r.read()
+    finally:
+        r.release()
+    got = _run_world(4, "gloo", tmp_path, 1, extra=("pipelined",), geom=(w, h, frames, stripe))
+    assert_fb_equal(got.reshape(-1, 4), want, "world-4 pipelined at 1024 x 1024 vs one process")
+
+
+@pytest.mark.parametrize("config,extra", [(3, ["--spp", "2"]), (4, ["--spp", "1"])])
+def test_bench_rehearses_four_ranks_on_the_named_multi_gpu_configs(device, config, extra):
+    """bench.py --gpus 4 --rehearse on BASELINE configs[3] (2048 x 2048) and configs[4] (the 10^6-triangle soup through the LBVH, every
+    rank building its own hierarchy): the N-rank code path of the two workloads BASELINE names for 8 GPUs, with the line's own record
+    of what the collective backend connected (ranks_seen, backend)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse", "--config", str(config), "--steps", "2", "--warmup", "1"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["backend"] == "gloo" and len(d["devices_seen"]) == 4
+    assert d["value"] > 0 and "rehearsal" in d
+
+
 def test_world2_nccl(device, cornell, tmp_path):
     from oclpathtracer_amd import shim
 

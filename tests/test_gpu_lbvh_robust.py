@@ -226,7 +226,12 @@ def test_grazing_rays_over_coplanar_tiles(device, oracle, delta):
     assert st["accept"] > 50, "the tiles must actually be hit"
     got1, _ = _render(device, tris, mats, W, H, frames, 1)
     assert_fb_equal(got1, want, "horizon tiles delta %g, brute force" % delta)
-    got2, gst = _render(device, tris, mats, W, H, frames, 2)
+    got2, gst = _render(device, tris, mats, W, H, frames, 2, tally=True)
+    from oclpathtracer_amd import shim
+    grazing, rays = int(gst[shim.PT_STAT_BVH_GRAZING]), int(gst[shim.PT_STAT_RAYS])
+    print("horizon tiles, delta %g: %d of %d rays ended in a hit at cos(incidence) < 1e-2 (the LBVH's unproven range)" % (delta, grazing, rays))
+    if delta <= 0.03:
+        assert grazing > 0, "this scene is built to put accepted hits into the unproven range"
     differ = int((got2.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum()) if got2.shape == want.shape else -1
     print("horizon tiles, delta %g (%d triangles): LBVH pixels that differ from the brute-force oracle: %d of %d; rms %.2e"
           % (delta, len(tris), differ, W * H, rms_diff(got2, want)))
@@ -266,3 +271,19 @@ def test_exposed_triangle_buffer_is_prepared_again(device, oracle, cornell):
     want = oracle.render(moved, mats, W, H, frames)
     assert not np.array_equal(first, second)
     assert_fb_equal(second, want, "after the rewrite through the raw pointer")
+
+
+def test_lbvh_exposure_of_the_configs4_soup(device):
+    """report the exposure instead of arguing it.  On BASELINE configs[4]'s scene (10^6-triangle soup, full image,
+    8 spp) the tallying build counts the accepted closest hits at cos(incidence) < 1e-2 -- outside the range over which the boxes'
+    margin is argued conservative (csrc/pt_bvh.hip).  Randomly oriented triangles put ~1e-4 of the hits there (the projected area of
+    a triangle seen at cos c is proportional to c: int_0^0.01 c dc / int_0^1 c dc); the count is printed for the README and bounded.
+    That these renders are nevertheless bit-exact against brute force is test_configs4_million_triangle_soup_full_size's business."""
+    from oclpathtracer_amd import scene, shim
+
+    tris, mats = scene.make_soup(1_000_000)
+    _, st = _render(device, tris, mats, 1024, 1024, 8, 0, tally=True)
+    grazing, rays = int(st[shim.PT_STAT_BVH_GRAZING]), int(st[shim.PT_STAT_RAYS])
+    print("configs[4] soup, 1024 x 1024 x 8 spp: %d of %d rays (%.2e) ended in a hit at cos(incidence) < 1e-2" % (grazing, rays, grazing / rays))
+    assert rays > 50_000_000
+    assert grazing / rays < 1.0e-3
