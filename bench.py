@@ -314,27 +314,31 @@ def soup_roofline(tally, rays_per_launch, samples_per_launch, avg_ms):
     alg_bytes = rays_per_launch * (tally["nodes_per_ray"] * B_BVH_NODE + tally["tris_per_ray"] * B_BVH_TRI) + samples_per_launch * 12.0
     tfl = flops / dt / 1e12
     pmc = soup_pmc()
-    peak_gbs = GATHER_CEILING_RECORDS_PER_S * GATHER_RECORD_BYTES / 1e9
+    gather_gbs = GATHER_CEILING_RECORDS_PER_S * GATHER_RECORD_BYTES / 1e9
     mem = None
     if pmc is not None:
         miss_per_s = pmc["l2_misses_per_ray"] * rays_per_launch / dt
         achieved = miss_per_s * GATHER_RECORD_BYTES / 1e9
         traffic = pmc["bytes_beyond_l2_per_ray"] * rays_per_launch
-        mem = {"bound": "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s", "frac": achieved / peak_gbs, "traffic": traffic,
+        # `peak` and `frac` against the hardware's HBM figure; what a dependent 64-byte gather can reach of it is a
+        # separate field.  The per-ray counters come from a COMMITTED rocprofv3 PMC pass (counters cannot be read inside the timed
+        # run), scaled by this launch's rays: the record says which file, so a stale one shows
+        mem = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
                "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms,
-               "peak_basis": "dependent random gather of 64-byte records from an 80 MB table, no arithmetic: %.1f G records/s "
-                             "(tools/ubench_gather, profiles/r03/ubench_gather_r03.txt) -- the ceiling of this access pattern; the HBM "
-                             "spec figure (8000 GB/s) is not reachable by dependent 64-byte gathers" % (GATHER_CEILING_RECORDS_PER_S / 1e9),
+               "from_committed_profile": True, "profile": pmc["file"],
                "achieved_basis": "%s: %.1f L2 misses per ray (hit rate %.1f %%) x %.4g rays of this launch / its duration = %.1f G misses/s, 64 bytes each"
                                  % (pmc["file"], pmc["l2_misses_per_ray"], 100.0 * pmc["l2_hit_rate"], rays_per_launch, miss_per_s / 1e9),
-               "frac_of_hbm_spec_peak": (traffic / dt / 1e9) / PEAK_HBM_GBS,
+               "gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
+               "gather_ceiling_basis": "dependent random gather of 64-byte records from an 80 MB table, no arithmetic: %.1f G records/s "
+                                       "(tools/ubench_gather, profiles/r03/ubench_gather_r03.txt) -- what this access pattern can reach of the HBM figure"
+                                       % (GATHER_CEILING_RECORDS_PER_S / 1e9),
                "algorithmic_bytes_per_launch": alg_bytes,
                "algorithmic_gbs": alg_bytes / dt / 1e9,
                "note": "algorithmic = 64 B per node entered + 48 B per triangle tested + 12 B radiance per sample: most of it is served by "
                        "L1 / L2 (upper tree levels), so it is NOT set against a memory peak; `traffic` = measured bytes beyond the L2 (FETCH_SIZE as "
-                       "tallied: 64 B per miss).  Round 3 (profiles/r03/lbvh_bottlenecks.txt, lbvh_steps.txt): neither the miss path (this fraction), "
-                       "nor VALU issue (`roofline_valu`, PMC: %.0f wave-instructions per ray), nor the L1's bandwidth is saturated alone; the search is "
-                       "balanced between them at five waves per SIMD (4 and 6 waves are both 10 %% slower)" % pmc["valu_instructions_per_ray"],
+                       "tallied: 64 B per miss).  Neither the miss path, nor VALU issue (`roofline_valu`, PMC: %.0f wave-instructions per ray), nor the "
+                       "L1's bandwidth is saturated alone; the search is balanced between them at five waves per SIMD (profiles/r03/lbvh_bottlenecks.txt)"
+                       % pmc["valu_instructions_per_ray"],
                **tally}
     valu = {"bound": "valu", "achieved": tfl, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_VALU_TFLOPS,
             "traffic": None, "kernel": "pt_trace_bvh_kernel", "avg_launch_ms": avg_ms, "algorithmic_flops_per_launch": flops,

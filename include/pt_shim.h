@@ -179,7 +179,11 @@ enum pt_option {
      * the last batch, every wave saving the paths it still holds, and the render's next launch resumes them -- so that walking
      * a render through the bounded staging ring in many short launches costs what one long launch costs; 0 = every launch
      * runs its paths out (A/B timing; always the case for LBVH renders).  Identical pixels either way. */
-    PT_OPT_CHECKPOINT = 10
+    PT_OPT_CHECKPOINT = 10,
+    /* read-only (pt_device_get_option): LBVH builds this handle has made.  A scene is built once; a triangle buffer the caller can
+     * write behind the ABI (pt_buffer_wrap, pt_buffer_device_ptr) is prepared again for every render, and built again only when the
+     * checksum of its records has changed. */
+    PT_OPT_BVH_BUILD_COUNT = 11
 };
 int pt_device_set_option(pt_device_t dev, int option, int64_t value);
 int64_t pt_device_get_option(pt_device_t dev, int option);

@@ -154,7 +154,8 @@ struct PtFoldParams {
 // triangles whose e2 is not the exact negation of their predecessor's (0 = the scene is all quads),
 // [2] bit pattern of max |vertex - eye|_inf, [3] number of odd triangles whose p1 is not their
 // predecessor's p3 (0 = every pair is (a,b,c),(c,d,a))
-#define PT_PREP_WORDS 4
+// [4], [5] (one 64-bit word): checksum of the raw records
+#define PT_PREP_WORDS 6
 hipError_t ptk_prep_triangles(const PtRawTriangle* raw, PtPrepTriangle* out, int ntri, unsigned int* det_bound_bits,
                               hipStream_t s);
 // quad mode 2: writes every odd record's pad0[0] = slack of its shared-u bound (needs the scene

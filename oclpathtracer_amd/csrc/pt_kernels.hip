@@ -104,6 +104,19 @@ __global__ void pt_prep_kernel(const PtRawTriangle* __restrict__ raw, PtPrepTria
         r = !(az <= r) ? az : r;
     }
     atomicMax(&det_bound_bits[2], __float_as_uint(r) & 0x7fffffffu);
+    // words 4, 5: a 64-bit checksum of the raw records (position-dependent mix per record, summed: order of arrival does not matter).
+    // A buffer the caller can write behind the ABI is prepared again for every render (pt_shim.hip); the checksum tells whether that
+    // changed anything, i.e. whether the LBVH and the primary-ray masks made from the previous contents still stand.
+    {
+        const unsigned* w = reinterpret_cast<const unsigned*>(raw + i);
+        unsigned long long h = 0x9e3779b97f4a7c15ull * (unsigned long long)(i + 1);
+        for (int k = 0; k < 16; ++k) {
+            h ^= (unsigned long long)w[k] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 33;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(det_bound_bits + 4), h);
+    }
 }
 
 // Second pass of the scene preparation for quad mode 2 (see pt_quad2_pass1 for the derivation):
@@ -1407,7 +1420,9 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
             return;   // (the tallies went with it)
         }
     }
+#if !PT_STAMPS   // (the diagnostic build reports its own figures in stats[2..7])
     if (P.stats && lane == 0 && n_carried != 0u) atomicAdd(&P.stats[7], (unsigned long long)n_carried);
+#endif
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 

@@ -96,6 +96,10 @@ struct pt_device_s {
     const pt_buffer_s* prep_src;
     uint64_t prep_version;
     int prep_ntri;
+    uint64_t prep_hash;         // checksum of the raw records the prepared scene was made from (pt_prep_kernel)
+    bool prep_hash_valid;
+    uint64_t scene_gen;         // bumped whenever the prepared scene's CONTENTS changed
+    uint64_t bvh_builds;        // LBVH builds so far (PT_OPT_BVH_BUILD_COUNT)
     bool prep_det_bounded;      // scene extent allows the short exact reciprocal
     int prep_quads;             // 0: independent triangles; 3: every pair (2k, 2k+1) is a quad (a,b,c),(c,d,a),
                                 // finite radius, margins and the packed table prepared
@@ -144,7 +148,7 @@ struct pt_device_s {
     size_t carry_waves;      // waves each of them holds
     uint2* pmask;            // primary-ray candidate masks of the local pixels (pt_primary_mask_kernel)
     size_t pmask_pixels;
-    struct { const void* src; uint64_t version; int32_t g[7]; bool valid; } pmask_key;  // what the masks in hand were made for
+    struct { uint64_t scene_gen; int32_t g[7]; bool valid; } pmask_key;  // what the masks in hand were made for
     unsigned int* counters;  // PT_QUEUE_COUNTERS work-queue counters, PT_QUEUE_STRIDE words apart: zero between launches
     bool counters_dirty;     // a failed call may have left one non-zero
     unsigned int* trav_host; // the LBVH's sticky "search cut short" words: host memory the kernels store to (PT_ERR_TRAVERSAL)
@@ -593,6 +597,7 @@ extern "C" int64_t pt_device_get_option(pt_device_t d, int option)
     case PT_OPT_BVH_STACK_LIMIT: return d->opt_bvh_stack;
     case PT_OPT_RENDER_LANES: return d->opt_lanes;
     case PT_OPT_CHECKPOINT: return d->opt_carry;
+    case PT_OPT_BVH_BUILD_COUNT: return (int64_t)d->bvh_builds;
     case PT_OPT_RESERVED_3: return 0;
     default: return -1;
     }
@@ -932,6 +937,7 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->bvh_valid = false;
         d->prep_capacity = 0;
         d->prep_src = nullptr;
+        d->prep_hash_valid = false;
         size_t cap = std::max<size_t>((size_t)ntri, 64);
         hipError_t e = ws_malloc(d, &d->prep, cap * sizeof(PtPrepTriangle));
         if (e == hipSuccess) e = ws_malloc(d, &d->p1tab, ptk_p1tab_floats((int)cap) * sizeof(float));
@@ -972,7 +978,15 @@ static int ensure_prep(pt_device_s* d, const pt_buffer_s* tris, int ntri)
         d->prep_p1_hi = (delta1 + deltaP) * 1.001f;
     }
     d->blocks_per_cu = ptk_trace_blocks_per_cu(ntri);  // the LDS footprint follows the scene
-    d->bvh_valid = false;
+    // Memory the caller can write behind the ABI is prepared again for every render; the checksum of the raw records says whether
+    // that changed anything -- if not, the LBVH (a radix sort, a build, host waits) and the primary-ray masks still stand
+    const uint64_t hash = (uint64_t)words[4] | ((uint64_t)words[5] << 32);
+    if (!(d->prep_src == tris && d->prep_ntri == ntri && d->prep_hash_valid && d->prep_hash == hash)) {
+        d->bvh_valid = false;
+        d->scene_gen++;
+    }
+    d->prep_hash = hash;
+    d->prep_hash_valid = true;
     d->prep_src = tris;
     d->prep_version = tris->version;
     d->prep_ntri = ntri;
@@ -1041,6 +1055,7 @@ static int ensure_bvh(pt_device_s* d, const pt_buffer_s* tris, int ntri)
     }
 #endif
     d->bvh_valid = true;
+    d->bvh_builds++;
     return PT_OK;
 }
 
@@ -1080,8 +1095,7 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
     bool make_pmask = false;
     if (use_pmask) {
         const int32_t g[7] = { rp.width, rp.height, rp.stripe_rows, rp.n_ranks, rp.rank, (int32_t)npix, rp.num_triangles };
-        make_pmask = !d->pmask_key.valid || d->pmask_key.src != (const void*)tris || d->pmask_key.version != tris->version ||
-                     memcmp(d->pmask_key.g, g, sizeof g) != 0 || !tris->owned || tris->exposed;
+        make_pmask = !d->pmask_key.valid || d->pmask_key.scene_gen != d->scene_gen || memcmp(d->pmask_key.g, g, sizeof g) != 0;
         if (make_pmask) {
             if ((rc = lanes_join(d))) return rc;   // (a render with the old masks may still be running)
             d->main_dirty = true;
@@ -1095,8 +1109,7 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
                 if (e != hipSuccess) return fail(PT_ERR_OOM, "primary-mask allocation (%zu bytes) failed: %s", (size_t)npix * sizeof(uint2), hipGetErrorString(e));
                 d->pmask_pixels = npix;
             }
-            d->pmask_key.src = tris;
-            d->pmask_key.version = tris->version;
+            d->pmask_key.scene_gen = d->scene_gen;
             memcpy(d->pmask_key.g, g, sizeof g);
         }
     }

@@ -17,7 +17,7 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_OOM, PT_ERR_HIP, PT_ERR_NOT_FOUND, PT_ERR_ARGS, PT_ERR_RANGE, PT_ERR_TRAVERSAL = range(1, 9)
 PT_INFO_NAME, PT_INFO_BOARD, PT_INFO_VENDOR, PT_INFO_VERSION = range(4)
 PT_OPT_BATCH_FRAMES, PT_OPT_CHUNK_FRAMES, PT_OPT_PROFILE_RETURN_TIME = 0, 1, 2   # (3 is not assigned)
-PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT_BVH_STACK_LIMIT, PT_OPT_RENDER_LANES, PT_OPT_CHECKPOINT = 4, 5, 6, 7, 8, 9, 10
+PT_OPT_QUAD_FILTER, PT_OPT_ACCEL, PT_OPT_BVH_TALLY, PT_OPT_PRIMARY_MASKS, PT_OPT_BVH_STACK_LIMIT, PT_OPT_RENDER_LANES, PT_OPT_CHECKPOINT, PT_OPT_BVH_BUILD_COUNT = 4, 5, 6, 7, 8, 9, 10, 11
 PT_SHIM_ABI_VERSION = 2  # include/pt_shim.h; load() refuses a library of another version
 PT_MAX_ARG_SIZE = 64
 PT_MAX_ARG_COUNT = 64

@@ -287,3 +287,42 @@ def test_lbvh_exposure_of_the_configs4_soup(device):
     print("configs[4] soup, 1024 x 1024 x 8 spp: %d of %d rays (%.2e) ended in a hit at cos(incidence) < 1e-2" % (grazing, rays, grazing / rays))
     assert rays > 50_000_000
     assert grazing / rays < 1.0e-3
+
+
+def test_exposed_scene_is_built_again_only_when_its_records_changed(device, oracle):
+    """a triangle buffer whose device pointer has been handed out is prepared again for every render -- and used to be BUILT
+    again for every render (radix sort, hierarchy, host waits), for the buffer's lifetime.  The prep kernel now returns a checksum of
+    the raw records: same contents, same hierarchy; changed contents, a new one."""
+    import ctypes
+
+    from oclpathtracer_amd import adl, scene, shim
+    from oclpathtracer_amd.render import Renderer
+
+    lib = shim.load()
+    tris, mats = scene.make_soup(3000)
+    W, H, frames = 48, 32, 2
+    r = Renderer(device, tris, mats, W, H)
+    try:
+        builds0 = lib.pt_device_get_option(device._h, shim.PT_OPT_BVH_BUILD_COUNT)
+        r.render(frames, frame_begin=0)
+        ptr = r.tbuf.getInternalObject()                     # exposes the device memory
+        for _ in range(3):
+            r.render(frames, frame_begin=0)
+        first = r.read()
+        assert lib.pt_device_get_option(device._h, shim.PT_OPT_BVH_BUILD_COUNT) == builds0 + 1
+        moved = tris.copy()
+        moved["p1"][40:, 1] += np.float32(0.25)
+        moved["p2"][40:, 1] += np.float32(0.25)
+        moved["p3"][40:, 1] += np.float32(0.25)
+        alias = adl.Buffer(dtype=scene.TRIANGLE_DTYPE)
+        alias.setRawPtr(device, ptr, len(tris))
+        alias.write(moved, len(moved))                       # behind r.tbuf's back
+        device.waitForCompletion()
+        alias.release()
+        r.render(frames, frame_begin=0)
+        second = r.read()
+        assert lib.pt_device_get_option(device._h, shim.PT_OPT_BVH_BUILD_COUNT) == builds0 + 2
+    finally:
+        r.release()
+    assert_fb_equal(first, oracle.render(tris, mats, W, H, frames), "before the rewrite")
+    assert_fb_equal(second, oracle.render(moved, mats, W, H, frames), "after the rewrite")

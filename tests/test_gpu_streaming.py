@@ -135,21 +135,26 @@ def test_renders_return_before_the_gpu_has_finished_and_overlap(device, cornell,
     tris, mats = cornell
     W, H, frames = 512, 512, 96
     want = oracle.render(tris, mats, W, H, frames)
-    rs = [Renderer(device, tris, mats, W, H) for _ in range(2)]
+    from oclpathtracer_amd import adl
+    r = Renderer(device, tris, mats, W, H)               # ONE scene (a second Renderer would upload a second copy, and alternating
+    fbs = [r.fb, adl.Buffer(device, W * H, adl.float4)]  # between them prepare the scene anew for every render), two framebuffers
     try:
-        rs[0].render(frames, frame_begin=0)
+        r.render(frames, frame_begin=0)
         device.waitForCompletion()
         t0 = time.perf_counter()
         for k in range(12):
-            rs[k & 1].render(frames, frame_begin=0)
+            r.render(frames, frame_begin=0, fb=fbs[k & 1])
         t_enqueue = time.perf_counter() - t0
         device.waitForCompletion()
         t_total = time.perf_counter() - t0
-        for r in rs:
-            assert_fb_equal(r.read(), want, "overlapped renders")
+        for fb in fbs:
+            got = np.empty((W * H, 4), np.float32)
+            fb.read(got, W * H)
+            device.waitForCompletion()
+            assert_fb_equal(got, want, "overlapped renders")
     finally:
-        for r in rs:
-            r.release()
+        fbs[1].release()
+        r.release()
     print("12 renders: enqueued in %.2f ms, finished after %.2f ms" % (t_enqueue * 1e3, t_total * 1e3))
     assert t_enqueue < 0.5 * t_total
 

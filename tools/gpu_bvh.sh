@@ -11,7 +11,8 @@ for lib in "$@"; do
     first=0
     timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "${BVH_TESTS:-bvh or soup or lbvh or random_quad or ties or golden or corner}" > gpurun_out/bvh_${tag}_pytest.log 2>&1
     rc=$?; echo "$lib pytest rc=$rc $(tail -1 gpurun_out/bvh_${tag}_pytest.log)"
-    [ $rc -ne 0 ] && { tail -30 gpurun_out/bvh_${tag}_pytest.log; echo "PARITY FAILED for $lib: the timings below are of a WRONG kernel"; }
+    # (a timing of a kernel that failed parity must not reach profiles/ or a DESIGN table by way of a missed log line)
+    [ $rc -ne 0 ] && { tail -30 gpurun_out/bvh_${tag}_pytest.log; echo "PARITY FAILED for $lib: no timing taken"; exit $rc; }
   fi
   timeout -k 10 300 python bench.py --soup 1000000 --spp 32 --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs > gpurun_out/bvh_${tag}_bench.log 2>&1
   python3 - <<PY

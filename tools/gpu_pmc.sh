@@ -8,7 +8,7 @@ REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 run_pass () {
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmc_${TAG}_$name -o pmc -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-extra-configs > $REPO/gpurun_out/pmc_${TAG}_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmc_${TAG}_$name -o pmc -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-extra-configs $BENCH_ARGS > $REPO/gpurun_out/pmc_${TAG}_$name.log 2>&1
   echo "pass $name rc=$?"
 }
 run_pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY

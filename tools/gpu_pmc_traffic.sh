@@ -4,7 +4,7 @@ set -o pipefail
 TAG=${1:-x}; SPP=${2:-256}; REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmct_${TAG}_$c -o pmc -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-extra-configs > $REPO/gpurun_out/pmct_${TAG}_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmct_${TAG}_$c -o pmc -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-extra-configs $BENCH_ARGS > $REPO/gpurun_out/pmct_${TAG}_$c.log 2>&1
 done
 cd $REPO
 python3 - <<PY

@@ -14,20 +14,23 @@ dev.setOption(shim.PT_OPT_RENDER_LANES, int(os.environ.get("PT_LANES", "2")))
 dev.setOption(shim.PT_OPT_CHECKPOINT, int(os.environ.get("PT_CHECKPOINT", "1")))
 dev.setOption(shim.PT_OPT_CHUNK_FRAMES, int(os.environ.get("PT_CHUNK", "0")))
 dev.reserveStaging(int(os.environ.get("PT_STAGING_MB", "0")) << 20)
-rs = [Renderer(dev, t, m, W, H) for _ in range(2)]   # two framebuffers, alternating (as bench.py's loop)
+r = Renderer(dev, t, m, W, H)
+fbs = [r.fb, adl.Buffer(dev, W * H, adl.float4)]   # one scene, two framebuffers, alternating (as bench.py's loop)
 for k in range(6):
-    rs[k & 1].render(spp, frame_begin=0, max_bounces=depth)
+    r.render(spp, frame_begin=0, max_bounces=depth, fb=fbs[k & 1])
 dev.waitForCompletion()
-best = 1e9
+best, enq = 1e9, 0.0
 for _ in range(3):
     t0 = time.perf_counter()
     for k in range(reps):
-        rs[k & 1].render(spp, frame_begin=0, max_bounces=depth)
+        r.render(spp, frame_begin=0, max_bounces=depth, fb=fbs[k & 1])
+    t1 = time.perf_counter()
     dev.waitForCompletion()
-    best = min(best, (time.perf_counter() - t0) / reps)
-print("%dx%d x %d spp depth %d: %.3f ms per render, %.1f Msamples/s (lanes %s checkpoint %s chunk %s staging %s MiB)"
-      % (W, H, spp, depth, best * 1e3, W * H * spp / best / 1e6, os.environ.get("PT_LANES", "2"), os.environ.get("PT_CHECKPOINT", "1"),
+    if (time.perf_counter() - t0) / reps < best:
+        best, enq = (time.perf_counter() - t0) / reps, (t1 - t0) / reps
+print("%dx%d x %d spp depth %d: %.3f ms per render (host: %.3f ms to enqueue it), %.1f Msamples/s (lanes %s checkpoint %s chunk %s staging %s MiB)"
+      % (W, H, spp, depth, best * 1e3, enq * 1e3, W * H * spp / best / 1e6, os.environ.get("PT_LANES", "2"), os.environ.get("PT_CHECKPOINT", "1"),
          os.environ.get("PT_CHUNK", "0"), os.environ.get("PT_STAGING_MB", "0")))
-for r in rs:
-    r.release()
+fbs[1].release()
+r.release()
 adl.DeviceUtils.deallocate(dev)
