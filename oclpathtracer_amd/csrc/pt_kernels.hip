@@ -896,9 +896,9 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         s.L = add3(s.L, scale3(s.mask, bg));  // :235
         finished = true;
     } else {
-        // The direction sample's angle first: sin/cos run in binary64 and are the register
-        // peak of the kernel; here only the path state is live.  Both BRDFs draw phi first,
-        // then the second uniform (:163-164, :182-183).
+        // The direction sample's angle first: here only the path state is live.  (pt_sincos takes its binary32 branch on every
+        // angle this path forms, phi in [0, 2 pi]; its binary64 branch is dead at run time.)  Both BRDFs draw phi first, then the
+        // second uniform (:163-164, :182-183).
         float phi = PTK_TWO_PI * pt_random_float(s.seed);
         float xi = pt_random_float(s.seed);
         float sp, cp;
