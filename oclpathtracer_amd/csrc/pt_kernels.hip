@@ -1079,8 +1079,10 @@ PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue&
         k = __builtin_amdgcn_readfirstlane(k);
         b = k * PT_QUEUE_SHARDS + sh;
         if (b < total) { got = true; break; }
-        empty_mask |= 1u << sh;
-        if (lane == 0u) atomicOr(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u << sh);
+        // (mark it, and see what the others have marked meanwhile: no grab at a shard known to be empty)
+        unsigned seen = 0u;
+        if (lane == 0u) seen = atomicOr(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u << sh);
+        empty_mask |= (1u << sh) | (unsigned)__builtin_amdgcn_readfirstlane(seen);
     }
     if (!got) { q.g = PT_Q_EMPTY; return false; }
     q.g = sh;
@@ -1185,6 +1187,34 @@ PTK_DEV void pt_carry_store(uint32_t* region, unsigned lane, const float4* pool,
         region[4] = n_rays;
         region[5] = n_samples;
         region[6] = n_carried + pool_n + (q.end - q.pix);
+    }
+}
+
+// the LBVH kernel's checkpoint: no pool -- the live lanes go to the region directly, compacted (its registers have room for it)
+PTK_DEV void pt_carry_store_lanes(uint32_t* region, unsigned lane, const PtPath& s, bool alive, const PtWaveQueue& q, unsigned n_rays, unsigned n_samples,
+                                  unsigned n_carried)
+{
+    float4* A = reinterpret_cast<float4*>(region + 16);
+    unsigned* W = region + 16 + PT_CARRY_RECORDS * 12;
+    const unsigned long long live = __ballot(alive);
+    const unsigned n_live = (unsigned)__popcll(live);
+    if (alive) {
+        const unsigned k = pt_mbcnt(live);
+        A[k] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+        A[PT_CARRY_RECORDS + k] = make_float4(s.d.y, s.d.z, s.mask.x, s.mask.y);
+        A[2 * PT_CARRY_RECORDS + k] = make_float4(s.mask.z, s.L.x, s.L.y, s.L.z);
+        W[k] = s.seed;
+        W[PT_CARRY_RECORDS + k] = s.lp;
+        W[2 * PT_CARRY_RECORDS + k] = s.fl | ((unsigned)s.bounce << 16);
+    }
+    if (lane == 0u) {
+        region[0] = n_live;
+        region[1] = q.pix;
+        region[2] = q.end;
+        region[3] = q.frame;
+        region[4] = n_rays;
+        region[5] = n_samples;
+        region[6] = n_carried + n_live + (q.end - q.pix);
     }
 }
 
@@ -1828,7 +1858,24 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
     s.o = mk3(0.0f, 0.0f, 0.0f); s.d = mk3(0.0f, 0.0f, 1.0f);
     s.mask = mk3(1.0f, 1.0f, 1.0f); s.L = mk3(0.0f, 0.0f, 0.0f);
     s.seed = 0; s.bounce = 0; s.lp = 0; s.fl = 0;
-    unsigned n_rays = 0, n_samples = 0;
+    unsigned n_rays = 0, n_samples = 0, n_carried = 0;
+    // checkpointed launches (PtTraceParams::carry), as in the table kernels: a launch whose queue has handed out its last batch stops
+    // starting searches -- the lanes still searching finish THAT search (a hundred node steps, not the up to sixteen bounces a path has
+    // left), are shaded, and what every lane then holds is a path about to start its next search: 60 bytes a lane, resumed by the next
+    // launch of the render.  A launch's end is one search deep instead of one path deep.
+    // (the fields only this needs are read from the kernarg segment where they are used, pt_kargs: the kernel's SGPRs are spoken for)
+    unsigned visits = 0u;   // (wave-uniform) passes through the refill point
+    bool parked = false;    // the lane's path is between two searches (shaded; its next search not begun): what a checkpoint holds
+    {
+        const pt_kargs_p K = pt_kargs();
+        const unsigned wave = blockIdx.x * (PT_TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (wave < K->carry_in_waves) {
+            const unsigned shard = q.g;
+            pt_carry_load<true>(P, K->carry + (size_t)wave * PT_CARRY_STRIDE_DW, lane, s, alive, q, n_rays, n_samples, n_carried);
+            q.g = shard;
+            parked = alive;
+        }
+    }
     PtBvhLane L;  // the search's state
     L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1;
     L.gbase = L.gm = L.oct = 0u; L.sp = 0; L.ix = L.iy = L.iz = 0.0f; L.budget = 0u;
@@ -1842,9 +1889,11 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 if (TALLY) ++c_tsteps;
                 pt_bvh_round<DET_BOUNDED>(P, L, tl, tl.wr - tl.rd, lane, s.o, s.d, n_recs);
             }
-            const unsigned long long shaded = __ballot(alive && !trav);
+            // (a lane that holds a path and is not searching has FINISHED a search -- unless the path is PARKED: shaded already and waiting
+            // for the checkpoint of a launch that is stopping, or just resumed from one; those start their next search below)
+            const unsigned long long shaded = __ballot(alive && !trav && !parked);
             n_rays += (unsigned)__popcll(shaded);
-            if (TALLY && alive && !trav && L.hidx >= 0) {
+            if (TALLY && alive && !trav && !parked && L.hidx >= 0) {
                 // the LBVH's exposure (pt_bvh.hip: no finite box margin is PROVABLY conservative for rays within a fraction of a degree
                 // of a triangle's plane; the margin covers cos(incidence) >= 1e-2 with a factor 10 to spare): accepted hits that lie
                 // outside that range.  cos(incidence) = |dir . n| / |n|, n = e2 x e1 (the prepared record's), |dir| = 1.
@@ -1853,10 +1902,35 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
                 const float dn = __builtin_fabsf(s.d.x * nx + s.d.y * ny + s.d.z * nz);
                 if (dn < 1.0e-2f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz)) ++c_graze;
             }
-            if (alive && !trav) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx);
+            if (alive && !trav && !parked) pt_shade<DET_BOUNDED, false>(P, s, alive, L.tmax, L.hu, L.hv, L.hidx);
             n_samples += (unsigned)__popcll(shaded & ~__ballot(alive));
+            // stop?  (carry_out launches: the queue has nothing left for this wave, and it holds nothing of the previous launch's chunk any
+            // more, whose fold follows this launch)
+            // (this point is passed every few node steps: the queue's stop word is polled at every 16th pass only; otherwise the wave learns
+            // that the queue is empty from its own grabs.  Either way q.g says so from then on, and what is left of the wave's batch
+            // travels with the checkpoint.  The kernarg fields are read only here.)
+            bool stopping = false;
+            if (q.g != PT_Q_EMPTY && (++visits & 15u) == 0u) {
+                const pt_kargs_p K = pt_kargs();
+                if (K->carry_out != 0u) {
+                    unsigned empty_mask = 0u;
+                    if (lane == 0u) empty_mask = __hip_atomic_load(K->batch_counter + PT_QUEUE_STOP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)__builtin_amdgcn_readfirstlane(empty_mask) == (1u << PT_QUEUE_SHARDS) - 1u) q.g = PT_Q_EMPTY;
+                }
+            }
+            if (q.g == PT_Q_EMPTY) {
+                const pt_kargs_p K = pt_kargs();
+                stopping = K->carry_out != 0u && !(q.pix != q.end && q.frame < K->chunk_f0) && __ballot(alive && s.fl < K->chunk_f0) == 0ull;
+            }
+            if (stopping) {
+                parked = alive && !trav;
+                if (__ballot(trav) == 0ull) break;   // every lane holds a path between two searches (or none): the checkpoint
+                pt_bvh_step<DET_BOUNDED, TALLY>(P, L, trav, s.o, s.d, stk, ovf, nxt, tl, lane, n_recs, c_nodes, c_leaves, c_steps, c_tsteps, c_maxsp);
+                continue;
+            }
             pt_regenerate_lanes<false>(P, lane, q, s, alive);
             const bool start = alive && !trav;
+            parked = false;
             if (__ballot(start) != 0ull) {
                 if (start) { L.tmax = 1e20f; L.hu = 0.0f; L.hv = 0.0f; L.hidx = -1; }
                 if (P.nbig > 0) {
@@ -1895,14 +1969,26 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
         }
         atomicMax(&P.stats[6], (unsigned long long)c_maxsp);  // deepest stack any ray of the launch needed
     }
+    {
+        // (a wave that left the loop because nothing was alive holds nothing -- no path, no rest of a batch: an empty checkpoint; its tallies
+        // travel with it either way)
+        const pt_kargs_p K = pt_kargs();
+        if (K->carry_out != 0u) {
+            const unsigned wave = blockIdx.x * (PT_TRACE_THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            pt_carry_store_lanes(K->carry + (size_t)wave * PT_CARRY_STRIDE_DW, lane, s, alive, q, n_rays, n_samples, n_carried);
+            return;
+        }
+    }
+    if (P.stats && lane == 0 && n_carried != 0u) atomicAdd(&P.stats[7], (unsigned long long)n_carried);
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
-#ifdef PT_BVH_WAVES
-#define PT_BVH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PT_BVH_WAVES, PT_BVH_WAVES)))
-#else
-#define PT_BVH_WAVES_ATTR
+// five waves per SIMD (96 VGPRs): what the search is balanced at (round 3: four and six are both 10 % slower); left to itself hipcc takes
+// 102 registers for the checkpointed body -- four waves
+#ifndef PT_BVH_WAVES
+#define PT_BVH_WAVES 5
 #endif
+#define PT_BVH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PT_BVH_WAVES, PT_BVH_WAVES)))
 template <bool DET_BOUNDED, bool TALLY, int BIGQ>
 __global__ __launch_bounds__(PT_TRACE_THREADS) PT_BVH_WAVES_ATTR
 void pt_trace_bvh_kernel(const PtTraceParams P)

@@ -1185,8 +1185,8 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         const uint64_t blocks_needed = ((uint64_t)bpf * (uint64_t)chunk + wg_waves - 1) / wg_waves;
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
     }
-    // checkpointed launches: the table kernels (the LBVH kernel's traversal state lives in LDS and scratch)
-    const bool carry = d->opt_carry && !use_bvh;
+    // checkpointed launches (PtTraceParams::carry): the table kernels stop at a fresh-phase boundary, the LBVH kernel between two searches
+    const bool carry = d->opt_carry != 0;
     // the lane: one per render when its launches are checkpointed (each resumes its predecessor); otherwise the CHUNKS alternate, so that
     // chunk c+1's launch becomes resident while chunk c's runs its paths out (an LBVH launch's tail is milliseconds of falling lane use)
     int ln = d->opt_lanes == 2 ? (int)(d->render_seq++ & 1u) : 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs[4] scene on one GPU: the shipped ring (16 launches per render, lanes alternate per chunk) against one launch per render, same box
 mkdir -p gpurun_out/r04
-for spec in "default:" "lanes1:--lanes 1" "onechunk:--staging-mb 6400 --lanes 1"; do
+for spec in "default:" "nocarry:--checkpoint 0" "onechunk:--staging-mb 6400 --lanes 1" "onechunk_nocarry:--staging-mb 6400 --lanes 1 --checkpoint 0"; do
   name=${spec%%:*}; args=${spec#*:}
   timeout -k 10 400 python bench.py --config 4 --steps 2 --warmup 1 $args > gpurun_out/r04/soup_$name.json 2> gpurun_out/r04/soup_$name.err || { tail -3 gpurun_out/r04/soup_$name.err; exit 1; }
   grep -h '^{' gpurun_out/r04/soup_$name.json | python3 -c "
