@@ -1450,7 +1450,7 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
             return;   // (the tallies went with it)
         }
     }
-#if !PT_STAMPS   // (the diagnostic build reports its own figures in stats[2..7])
+#if !PT_STAMPS && !PT_VALIDATE_FILTER   // (the diagnostic builds report their own figures in stats[2..7])
     if (P.stats && lane == 0 && n_carried != 0u) atomicAdd(&P.stats[7], (unsigned long long)n_carried);
 #endif
     pt_flush_counters(P, lane, n_rays, n_samples);
@@ -1979,7 +1979,9 @@ PTK_DEV void pt_trace_bvh_body(const PtTraceParams& P)
             return;
         }
     }
+#if !PT_VALIDATE_FILTER
     if (P.stats && lane == 0 && n_carried != 0u) atomicAdd(&P.stats[7], (unsigned long long)n_carried);
+#endif
     pt_flush_counters(P, lane, n_rays, n_samples);
 }
 
