@@ -997,10 +997,12 @@ PTK_DEV void pt_shade(const PtTraceParams& P, PtPath& s, bool& alive, float tmax
         // pmc_r02_summary.txt: 35.2 bytes of HBM traffic per sample against 41.0 with aligned 16-byte records --
         // the L2 cannot hold every partly filled line of the ~900 000 paths in flight until it is complete, and a
         // partly written sector costs a read-modify-write either way; fewer bytes written, fewer sectors touched)
-        // (frame f of the render: entry (f + phase) % 2S of the staging ring, the first S entries in one slot, the others in the other)
-        const unsigned fr = s.fl + PT_ARG(ring_phase), S = PT_ARG(slot_frames);
-        const unsigned r = fr - __umulhi(fr, PT_ARG(ring_magic)) * (2u * S);
-        float* out = (r < S ? PT_ARG(rad) : PT_ARG(rad1)) + ((size_t)(r < S ? r : r - S) * PT_ARG(npix_local) + s.lp) * 3u;
+        // (frame f of the render: entry (f + phase) % 2S of the staging ring, the first S entries in one slot, the others in the other.
+        // Read from the kernarg segment here whichever the kernel: once per finished path, and six SGPRs the LBVH kernel does not have)
+        const pt_kargs_p KR = pt_kargs();
+        const unsigned fr = s.fl + KR->ring_phase, S = KR->slot_frames;
+        const unsigned r = fr - __umulhi(fr, KR->ring_magic) * (2u * S);
+        float* out = (r < S ? KR->rad : KR->rad1) + ((size_t)(r < S ? r : r - S) * KR->npix_local + s.lp) * 3u;
         // (records are 12 bytes apart: the vector type is declared with the 4-byte alignment the address really has)
         typedef float pt_f3v __attribute__((ext_vector_type(3), aligned(4)));
         pt_f3v v;
@@ -1529,7 +1531,7 @@ PTK_DEV void pt_regenerate_lanes(const PtTraceParams& P, unsigned lane, PtWaveQu
 {
     const pt_kargs_p K = pt_kargs();
     unsigned long long need = __ballot(!alive);
-    while (need != 0ull && pt_queue_refill<LATE>(P, lane, q, 0u)) {
+    while (need != 0ull && pt_queue_refill<true>(P, lane, q, 0u)) {   // (once per batch: its arguments come from the kernarg segment whichever the kernel)
         const unsigned n_need = (unsigned)__popcll(need);
         const unsigned avail = q.end - q.pix;
         const unsigned take = n_need < avail ? n_need : avail;

@@ -127,8 +127,9 @@ struct pt_device_s {
     // batch, every wave saving the paths it still holds, and T(c+1) resumes them beside its own samples -- a launch has no tail
     // of waves running out of paths, so chunks as short as a 192 MiB slot forces cost what one long launch costs.  F(c), the
     // fold of chunk c into the framebuffer, therefore follows T(c+1), which finishes chunk c's last paths; D is a launch with an
-    // empty queue that finishes the last chunk's.  (The LBVH kernel keeps its traversal state in LDS and scratch and is not
-    // checkpointed: T(0) F(0) T(1) F(1) ..., every launch runs its paths out.)
+    // empty queue that finishes the last chunk's.  (The LBVH kernel's checkpoint is one SEARCH deep: a stopping launch starts no new
+    // search, the lanes still searching finish theirs and are shaded, and the paths between two searches go to the next launch.
+    // With PT_OPT_CHECKPOINT 0 every launch runs its paths out and the CHUNKS alternate lanes: T(0) F(0) T(1) F(1) ...)
     // Consecutive renders ALTERNATE between the two lanes: render k+1's T(0) needs the slot that F(n-2) of render k released, not
     // the one F(n-1) is still to read, so it fills the machine while D of render k runs dry.  The folds of all chunks of all renders
     // form ONE chain (events): every pixel folds its frames in ascending order (GenerateColors.cl:314-321).

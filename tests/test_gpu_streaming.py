@@ -255,3 +255,36 @@ def test_a_render_longer_than_32768_frames_goes_in_parts(device, cornell, oracle
     got, st = _render(device, tris, mats, W, H, frames)
     assert_fb_equal(got, want, "33 068 frames of a 4x4 image")
     assert int(st[0]) == W * H * frames
+
+
+def test_a_callers_stream_keeps_plain_stream_order(device, cornell, oracle):
+    """pt_device_set_stream: the handle runs ON a stream of the caller's, who is promised stream order without events -- a torch op
+    enqueued on that stream right after a render reads the finished framebuffer, and a render enqueued right after a torch fill of
+    the framebuffer's neighbour does not start before it (the lanes fork behind the stream and the stream joins them, every render)."""
+    import torch
+
+    from oclpathtracer_amd import shim
+    from oclpathtracer_amd.render import Renderer
+
+    tris, mats = cornell
+    W, H, frames = 160, 120, 24
+    want = oracle.render(tris, mats, W, H, frames)
+    lib = shim.load()
+    st = torch.cuda.Stream()
+    t = torch.empty((H * W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    shim.check(lib.pt_device_set_stream(device._h, ctypes.c_void_p(st.cuda_stream)))
+    try:
+        r = Renderer(device, tris, mats, W, H, fb_device_ptr=t.data_ptr())
+        with torch.cuda.stream(st):
+            t.fill_(7.0)                              # on the caller's stream, before the render: must not land on top of it
+            r.render(frames, frame_begin=0)
+            snap = t.clone()                          # ... and right behind it, no event: stream order alone
+            r.render(5, frame_begin=0, max_bounces=1)
+            snap2 = t.clone()
+        st.synchronize()
+        assert_fb_equal(snap.cpu().numpy(), want, "torch op right behind a render on the caller's stream")
+        assert_fb_equal(snap2.cpu().numpy(), oracle.render(tris, mats, W, H, 5, max_bounces=1), "second render on the caller's stream")
+        r.release()
+    finally:
+        shim.check(lib.pt_device_set_stream(device._h, None))

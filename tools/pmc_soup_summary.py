@@ -2,8 +2,9 @@
 """Summarise the rocprofv3 PMC passes of tools/gpu_pmc_soup.sh (gpurun_out/pmcsoup_<tag>_*) per traced ray.
 
 usage: tools/pmc_soup_summary.py <tag> <spp of the timed render> [out.txt [out.json]]
-The profiled command renders the soup twice: `spp` frames (timed) and 16 frames (the tallied render of bench.py's roofline);
-both dispatches of pt_trace_bvh_kernel are summed and divided by the rays of both (samples x rays per sample of the bench line).
+The profiled command renders the soup twice: `spp` frames (the timed kernel) and 16 frames (the tallied render of bench.py's roofline, the
+measurement variant of the kernel: heavier, never timed).  Only the dispatches of the TIMED variant (template argument TALLY = false) are
+summed, and divided by the rays of its `spp` frames (samples x rays per sample of the bench line).  (Rounds 2 and 3 summed both variants.)
 """
 import collections
 import csv
@@ -17,7 +18,7 @@ agg = collections.defaultdict(float)
 for d in sorted(glob.glob("gpurun_out/pmcsoup_%s_*/" % tag)):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "pt_trace_bvh_kernel" in r["Kernel_Name"]:
+            if "pt_trace_bvh_kernel" in r["Kernel_Name"] and ", false, " in r["Kernel_Name"]:   # <DET_BOUNDED, TALLY = false, BIGQ>
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
 rps = None
 for f in glob.glob("gpurun_out/pmcsoup_%s_*.log" % tag):
@@ -28,9 +29,9 @@ for f in glob.glob("gpurun_out/pmcsoup_%s_*.log" % tag):
             W = H = 1024
 if rps is None:
     raise SystemExit("no bench line found in gpurun_out/pmcsoup_%s_*.log" % tag)
-rays = W * H * (spp + 16) * rps
-lines = ["10^6-triangle soup, 1024^2 x (%d + 16 tally) spp, rocprofv3 --pmc passes (tools/gpu_pmc_soup.sh %s %d); sums over both dispatches of"
-         % (spp, tag, spp), "pt_trace_bvh_kernel; %.4g rays" % rays]
+rays = W * H * spp * rps
+lines = ["10^6-triangle soup, 1024^2 x %d spp, rocprofv3 --pmc passes (tools/gpu_pmc_soup.sh %s %d); sums over the dispatches of the timed variant of"
+         % (spp, tag, spp), "pt_trace_bvh_kernel (TALLY = false); %.4g rays" % rays]
 for k in sorted(agg):
     lines.append("  %-34s %-14.6g (%.4g per ray)" % (k, agg[k], agg[k] / rays))
 g = lambda k: agg.get(k, 0.0)
