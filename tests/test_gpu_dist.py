@@ -227,3 +227,28 @@ def test_bench_starts_its_own_ranks(device):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["config"]["rays_per_sample"] > 1.0
+
+
+def test_bench_line_keeps_the_drivers_contract(device):
+    """The one JSON line `python bench.py` prints on one GPU: every field the driver and the judge read, with the types they expect
+    (a small image so that the CPU leg and the extra legs stay short; the numbers themselves are the record run's business)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra-configs"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "alloc_ms", "ranks_seen"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["scaling"] in ("weak", "strong")
+    assert "configs[2]" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - 1024 * 1024 * 256 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma", "valu") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s"
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "Msamples/s" and c["sample"]
+    assert d["config"]["workspace_bytes"] <= 512 * 1000 * 1000 and d["config"]["staging_ring_bytes"] == 2 * 192 * (1 << 20)
