@@ -693,6 +693,9 @@ PTK_DEV void pt_quad3_pass1(pt_const_f32p t, const PtRay3& r, pt_f2& un, pt_f2& 
 #ifndef PT_STAMPS
 #define PT_STAMPS 0
 #endif
+#ifndef PT_LAUNCH_STAMPS
+#define PT_LAUNCH_STAMPS 0   // DIAGNOSTIC build (tools/launch_stamps.py): start / first stop / last exit of one checkpointed launch
+#endif
 #if PT_STAMPS
 #define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -1085,6 +1088,11 @@ PTK_DEV bool pt_queue_refill(const PtTraceParams& P, unsigned lane, PtWaveQueue&
         unsigned seen = 0u;
         if (lane == 0u) seen = atomicOr(PT_ARG(batch_counter) + PT_QUEUE_STOP_WORD, 1u << sh);
         empty_mask |= (1u << sh) | (unsigned)__builtin_amdgcn_readfirstlane(seen);
+#if PT_LAUNCH_STAMPS
+        if (lane == 0u && PT_ARG(stats) != nullptr && (((unsigned)__builtin_amdgcn_readfirstlane(seen) | (1u << sh)) == (1u << PT_QUEUE_SHARDS) - 1u) &&
+            (unsigned)__builtin_amdgcn_readfirstlane(seen) != (1u << PT_QUEUE_SHARDS) - 1u && PT_ARG(stats)[13] * PT_ARG(slot_frames) == PT_ARG(chunk_f0))
+            atomicMin(&PT_ARG(stats)[14], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // the moment the stop word became complete
+#endif
     }
     if (!got) { q.g = PT_Q_EMPTY; return false; }
     q.g = sh;
@@ -1364,6 +1372,13 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
     if (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg < P.carry_in_waves)
         pt_carry_load<true>(P, P.carry + (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) * PT_CARRY_STRIDE_DW, lane, s, alive, q, n_rays, n_samples, n_carried);
     q.g = (blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) & (PT_QUEUE_SHARDS - 1u);   // the wave's first shard of this launch's queue
+#if PT_LAUNCH_STAMPS   // DIAGNOSTIC build (tools/launch_stamps.py): where a checkpointed launch's time goes -- s_memrealtime (100 MHz) of the
+    // first wave's start, the moment the stop word is complete, the last wave's exit; stats[9..12]
+    const unsigned long long ls_start = __builtin_amdgcn_s_memrealtime();
+    bool ls_saw_stop = false;
+    unsigned ls_boundaries = 0u, ls_iters = 0u, ls_iters_at_boundary = 0u;
+    unsigned long long ls_t_boundary = ls_start;
+#endif
 #if PT_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, c_regen = 0, c_loop = 0, c_shade = 0, c_iters = 0, c_steps = 0, c_p1 = 0;
 #endif
@@ -1378,8 +1393,15 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         if (__ballot(!alive) != 0ull) {
             if (pool_n == 0u) {
                 const int next = pt_queue_next<true>(P, lane, q, s, alive);
+#if PT_LAUNCH_STAMPS
+                ++ls_boundaries;
+                if (next != 2) { ls_t_boundary = __builtin_amdgcn_s_memrealtime(); ls_iters_at_boundary = ls_iters; }
+#endif
                 if (next != 0) {
                     pt_pool_push(pool, pool_n, s, alive);                // park every live path ...
+#if PT_LAUNCH_STAMPS
+                    if (next == 2) ls_saw_stop = true;
+#endif
                     if (next == 2) break;                                // ... for the next launch (a checkpoint) ...
                     primary = pt_start_fresh<true>(P, lane, q, s, alive);      // ... or start 64 coherent primary rays
                 }
@@ -1387,6 +1409,9 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
             pt_pool_pop(pool, pool_n, s, alive);           // dead lanes resume parked paths
         }
         if (__ballot(alive) == 0ull) break;
+#if PT_LAUNCH_STAMPS
+        ++ls_iters;
+#endif
         PT_STAMP(t1);
 
         // ---- intersectWorld (:137-154) ------------------------------------------------------
@@ -1448,6 +1473,19 @@ PTK_DEV void pt_trace_body(const PtTraceParams& P)
         // (a wave that left the loop because nothing was alive holds nothing: no parked path, no rest of a batch -- an empty checkpoint)
         const pt_kargs_p K = pt_kargs();
         if (K->carry_out != 0u) {
+#if PT_LAUNCH_STAMPS
+            // per wave, plain stores into the CALLER'S oversized stats buffer (16 + 4 * waves words): no atomics on a shared line -- those,
+            // 8 192 waves leaving together, backed the L2 channel up and slowed the waves still running five-fold (the first version
+            // of this diagnostic measured its own congestion)
+            if (K->stats != nullptr && lane == 0u && K->stats[13] * K->slot_frames == K->chunk_f0) {   // (stats[13]: which chunk's launch to stamp)
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                unsigned long long* mine = K->stats + 16 + 4u * (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg);
+                mine[0] = ls_start;
+                mine[1] = ls_t_boundary;
+                mine[2] = now;
+                mine[3] = ((unsigned long long)ls_boundaries << 40) | ((unsigned long long)(ls_iters - ls_iters_at_boundary) << 20) | ls_iters | (ls_saw_stop ? 1ull << 63 : 0ull);
+            }
+#endif
             pt_carry_store(K->carry + (size_t)(blockIdx.x * (PT_TRACE_THREADS / 64) + wave_in_wg) * PT_CARRY_STRIDE_DW, lane, pool, pool_n, q, n_rays, n_samples, n_carried);
             return;   // (the tallies went with it)
         }
