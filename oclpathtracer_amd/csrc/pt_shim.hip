@@ -1187,7 +1187,9 @@ static int render_part(pt_device_s* d, pt_buffer_s* tris, pt_buffer_s* mats, pt_
         if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
     }
     // checkpointed launches (PtTraceParams::carry): the table kernels stop at a fresh-phase boundary, the LBVH kernel between two searches
-    const bool carry = d->opt_carry != 0;
+    // (a render of ONE chunk has nothing to hand on: its only launch runs its paths out, beside the next render's first launch on the other lane --
+    // a checkpoint would add the draining launch and the checkpoint's traffic for nothing: 30.64 against 30.41 ms per one-launch configs[2] render)
+    const bool carry = d->opt_carry != 0 && nchunks > 1;
     // the lane: one per render when its launches are checkpointed (each resumes its predecessor); otherwise the CHUNKS alternate, so that
     // chunk c+1's launch becomes resident while chunk c's runs its paths out (an LBVH launch's tail is milliseconds of falling lane use)
     int ln = d->opt_lanes == 2 ? (int)(d->render_seq++ & 1u) : 0;
