@@ -25,6 +25,14 @@ for k in ("trace", "fold"):
                     g(k, "SQ_INSTS_VMEM_RD"), g(k, "SQ_INSTS_VMEM_WR"), int(g(k, "SQ_WAVES"))))
     lines.append("    SQ_BUSY_CYCLES %.4g  SQ_WAVE_CYCLES %.4g  SQ_WAIT_INST_ANY %.4g  GRBM_GUI_ACTIVE %.4g (/8 XCDs = %.4g)"
                  % (g(k, "SQ_BUSY_CYCLES"), g(k, "SQ_WAVE_CYCLES"), g(k, "SQ_WAIT_INST_ANY"), g(k, "GRBM_GUI_ACTIVE"), g(k, "GRBM_GUI_ACTIVE") / 8))
+    # (MI355X_MICROARCH.md: the SQ counters count quad-cycles; a wave64 vector instruction holds the issue for one quad and the SIMD sustains two per quad)
+    quads = g(k, "GRBM_GUI_ACTIVE") / 8 / 4 * 1024
+    if quads > 0 and g(k, "SQ_ACTIVE_INST_VALU") > 0:
+        lines.append("    vector-ALU issue: SQ_ACTIVE_INST_VALU %.4g quad-cycles over 1 024 SIMDs x %.4g quad-cycles of GRBM_GUI_ACTIVE / 8 = %.2f per SIMD and quad-cycle, "
+                     "%.0f %% of the two a SIMD sustains (v_fma_f32, wave64: 2 cycles); per wave: issuing %.0f %%, issue-stalled %.0f %%, parked in a wait %.0f %% of its cycles"
+                     % (g(k, "SQ_ACTIVE_INST_VALU"), quads / 1024, g(k, "SQ_ACTIVE_INST_VALU") / quads, 50.0 * g(k, "SQ_ACTIVE_INST_VALU") / quads,
+                        100.0 * g(k, "SQ_ACTIVE_INST_ANY") / max(g(k, "SQ_WAVE_CYCLES"), 1), 100.0 * g(k, "SQ_WAIT_INST_ANY") / max(g(k, "SQ_WAVE_CYCLES"), 1),
+                        100.0 * g(k, "SQ_WAIT_ANY") / max(g(k, "SQ_WAVE_CYCLES"), 1)))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/gpu_pmc.sh %s %d: bench.py --spp %d --steps 1 (the full configs[2] render: "
                  "every trace and fold launch of it summed), units KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE under-reports wide "
                  "streaming reads by 2x, MI355X_MICROARCH.md HBM).  These are bytes beyond the L2; the Infinity Cache lies behind it" % (tag, spp, spp),
