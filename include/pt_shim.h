@@ -177,8 +177,9 @@ enum pt_option {
     PT_OPT_RENDER_LANES = 9,
     /* 1 (default): the trace launches of a render are CHECKPOINTED -- a launch ends the moment its work queue has handed out
      * the last batch, every wave saving the paths it still holds, and the render's next launch resumes them -- so that walking
-     * a render through the bounded staging ring in many short launches costs what one long launch costs; 0 = every launch
-     * runs its paths out (A/B timing).  The LBVH kernel's checkpoint is one search deep: a stopping launch lets every lane finish its
+     * a render through the bounded staging ring in many short launches costs 5 % over one long launch (measured: DESIGN.md S6), not a
+     * tail of falling lane use per launch; a render of ONE chunk is one launch and takes no checkpoint; 0 = every launch runs its
+     * paths out (A/B timing).  The LBVH kernel's checkpoint is one search deep: a stopping launch lets every lane finish its
      * current search and hands the shaded paths on.  Identical pixels either way. */
     PT_OPT_CHECKPOINT = 10,
     /* read-only (pt_device_get_option): LBVH builds this handle has made.  A scene is built once; a triangle buffer the caller can
