@@ -125,7 +125,7 @@ struct pt_device_s {
     //     T(0)  T(1) F(0)  T(2) F(1)  ...  T(n-1) F(n-2)  D  F(n-1)
     // T(c) = trace launch of chunk c, CHECKPOINTED (PtTraceParams::carry): it ends the moment its queue has handed out the last
     // batch, every wave saving the paths it still holds, and T(c+1) resumes them beside its own samples -- a launch has no tail
-    // of waves running out of paths, so chunks as short as a 192 MiB slot forces cost what one long launch costs.  F(c), the
+    // of waves running out of paths, so chunks as short as a 192 MiB slot forces cost 5 % over one long launch (the waves stop over ~100 us, and a fold follows: DESIGN.md S6).  F(c), the
     // fold of chunk c into the framebuffer, therefore follows T(c+1), which finishes chunk c's last paths; D is a launch with an
     // empty queue that finishes the last chunk's.  (The LBVH kernel's checkpoint is one SEARCH deep: a stopping launch starts no new
     // search, the lanes still searching finish theirs and are shaded, and the paths between two searches go to the next launch.
